@@ -1,0 +1,183 @@
+/*
+ * trunet_hip.h -- C ABI of libtrunet_hip.so: the MI355X (gfx950) hot path of TRU-Net.
+ *
+ * The reference (Okrio/tinyrecurrentunet) has no FFI: its hot path is plain PyTorch module
+ * calls.  Every entry point below replaces the ATen/cuDNN/cuFFT work behind one reference
+ * call site (cited per function as file:line of /root/reference).  Conventions:
+ *   - extern "C", plain pointers + sizes, no torch types; all pointers are DEVICE pointers
+ *     unless named h_*; every call is asynchronous on `stream` (a hipStream_t passed as void*).
+ *   - returns 0 on success, a negative TRUNET_E* code otherwise; never throws, never
+ *     allocates or frees caller memory, keeps no global mutable state.
+ *   - all arithmetic is fp32 ("f32"); BatchNorm statistics are reduced in fp64.
+ *
+ * Internal activation layout ("frames-last"): a tensor of C channels x L positions for N frames
+ * is stored as float[C][L][NP] with NP = N rounded up to a multiple of 128; element
+ * (c,l,n) lives at ((c*L + l)*NP + n).  Frames (the batch axis of network.py) are the contiguous
+ * axis, so every conv tap / stride / pad / crop of network.py becomes a whole-row offset.
+ */
+#ifndef TRUNET_HIP_H
+#define TRUNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRUNET_OK 0
+#define TRUNET_EINVAL (-1)   /* bad argument (shape, alignment, null pointer) */
+#define TRUNET_ELAUNCH (-2)  /* HIP launch failure */
+#define TRUNET_ENOTSUP (-3)  /* configuration outside what the kernels were built for */
+
+#define TRUNET_TILE_FRAMES 128
+#define TRUNET_MAX_SEG 5
+
+/* B-operand prologue applied while staging rows into LDS */
+enum { TRUNET_PRO_NONE = 0,   /* v                                   */
+       TRUNET_PRO_BNRELU = 1, /* max(v*c0[ch] + c1[ch], 0)            (BatchNorm1d+ReLU, network.py:31-32) */
+       TRUNET_PRO_BNBWD = 2   /* c0[ch]*v + c1[ch]*v2 + c2[ch]        (BatchNorm backward, v=dy, v2=z)     */ };
+
+/* One K-segment of an implicit GEMM row: `nchan` channel rows of a frames-last tensor taken at
+ * position q(p) = (p*pos_mul + pos_off)/pos_div (segment skipped when q is fractional/out of range). */
+typedef struct {
+    const float* src0;  /* [nchan][L][NP] */
+    const float* src1;  /* second tensor for TRUNET_PRO_BNBWD, same shape; else NULL */
+    const float* c0;    /* per-channel coefficient arrays (see prologue), may be NULL for PRO_NONE */
+    const float* c1;
+    const float* c2;
+    int32_t nchan;
+    int32_t L;
+    int32_t pos_mul, pos_off, pos_div;
+    int32_t woff;       /* weight offset of this segment: A(m,c) = W[(m+w_m_off)*ldw_m + c*ldw_c + woff] */
+    int32_t mode;       /* TRUNET_PRO_* */
+    int32_t _pad;
+} trunet_seg;
+
+enum { TRUNET_EPI_BIAS = 1,   /* add bias[m]                                                      */
+       TRUNET_EPI_STATS = 2,  /* accumulate per-channel statistics into `partials`                 */
+       TRUNET_EPI_ACCUM = 4,  /* add the value already stored at the output location               */
+       TRUNET_EPI_MASK = 8,   /* multiply by [e0[m]*zmask + e1[m] > 0] (ReLU backward)              */
+       TRUNET_EPI_RELU = 16   /* max(.,0) before the store                                          */ };
+
+/* Implicit-GEMM conv (forward of Conv1d k=1 / ConvTranspose1d, and their data gradients):
+ *   out[m][p+out_pos_off][n] = epi( sum_seg sum_c A_seg(m,c) * pro_seg(src_seg[c][q_seg(p)][n]) )
+ * Replaces: nn.Conv1d(k=1) network.py:28,50,64,83,106; nn.ConvTranspose1d network.py:67,86,109;
+ * F.pad + torch.cat network.py:96-98,116-118 (two segments, no copy); nn.GRU input projection
+ * network.py:48; and the autograd backward of each.  Statistics (EPI_STATS): per channel
+ * sum(v), sum(v*v) (forward BatchNorm) or, with EPI_MASK, sum(dy), sum(dy*(zmask-e2[m])) (BatchNorm
+ * backward); one partial row per (workgroup, wave column group): partials[part][M_stat][2]. */
+typedef struct {
+    int32_t NP, N;            /* padded / valid frames */
+    int32_t P, p_begin;       /* output positions p_begin .. p_begin+P-1 */
+    int32_t M;                /* output channels of this launch (rows of A) */
+    int32_t m_out_off;        /* channel offset in `out`, bias, e*, partials */
+    int32_t out_L, out_pos_off;
+    int32_t ldw_m, ldw_c, w_m_off;
+    int32_t nseg;
+    int32_t epi;              /* TRUNET_EPI_* flags */
+    int32_t M_stat;           /* channel count of the statistics rows */
+    float* out;               /* [*][out_L][NP] */
+    const float* W;
+    const float* bias;
+    const float* zmask;       /* tensor shaped like out (EPI_MASK) */
+    const float* e0; const float* e1; const float* e2;
+    float* partials;          /* [nparts][M_stat][2] */
+    trunet_seg seg[TRUNET_MAX_SEG];
+} trunet_gemm_args;
+
+/* number of partial rows a trunet_conv_gemm launch writes (so the caller can size `partials`) */
+int trunet_conv_gemm_nparts(int M);
+int trunet_conv_gemm(const trunet_gemm_args* h_args, void* stream);
+
+/* Weight gradient of the same implicit GEMM (autograd of network.py:28,50,64,67,83,86,106,109,48):
+ *   dW[(m+w_m_off)*ldw_m + c*ldw_c + woff_seg] = sum_{p,n<N} dz[m][p][n] * pro_seg(src_seg[c][q_seg(p)][n])
+ * with dz = proA(a0[m][p][n], a1[m][p][n]).  Writes per-workgroup partial images of W (and of the
+ * bias gradient sum_{p,n} dz) that trunet_reduce_partials sums. */
+typedef struct {
+    int32_t NP, N;
+    int32_t P, p_begin;
+    int32_t M;                 /* rows of dz handled by this launch (<=128) */
+    int32_t a_L, a_pos_off;    /* dz tensors are [*][a_L][NP]; row position p + a_pos_off */
+    int32_t a_m_off;           /* channel offset inside the dz tensors / coefficient arrays */
+    int32_t a_mode;            /* TRUNET_PRO_NONE or TRUNET_PRO_BNBWD */
+    int32_t ldw_m, ldw_c, w_m_off;
+    int32_t nseg;
+    int32_t w_numel;           /* elements of one partial W image */
+    int32_t _pad;
+    const float* a0; const float* a1;
+    const float* ac0; const float* ac1; const float* ac2;
+    float* w_partials;         /* [nparts][w_numel], ZERO-FILLED by the caller */
+    float* b_partials;         /* [nparts][M_total_bias] or NULL */
+    int32_t b_stride, b_off;   /* bias partial row length / channel offset */
+    trunet_seg seg[TRUNET_MAX_SEG];
+} trunet_wgrad_args;
+
+int trunet_conv_wgrad_nparts(void);
+int trunet_conv_wgrad(const trunet_wgrad_args* h_args, void* stream);
+
+/* out[i] (+)= sum_g partials[g][i]  (deterministic second stage of every split reduction) */
+int trunet_reduce_partials(float* out, const float* partials, int nparts, int numel, int accumulate,
+                           void* stream);
+
+/* BatchNorm1d training statistics -> affine (network.py:31,39,51,65,72 ...; torch semantics:
+ * biased variance for normalisation, unbiased for running_var, momentum 0.1, eps 1e-5).
+ * partials: [nparts][C][2] = sum, sumsq.  Writes scale = gamma*rstd, shift = beta - mean*scale,
+ * mean, rstd; updates running_mean / running_var in place when non-NULL. */
+int trunet_bn_finalize_fwd(const float* partials, int nparts, int C, double count, const float* gamma,
+                           const float* beta, float eps, float momentum, float* running_mean,
+                           float* running_var, float* scale, float* shift, float* mean, float* rstd,
+                           void* stream);
+/* eval mode: scale/shift from running statistics */
+int trunet_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean,
+                          const float* running_var, float eps, float* scale, float* shift, void* stream);
+/* BatchNorm backward reduction: partials [nparts][C][2] = sum(dy), sum(dy*(z-mean)).
+ * Writes dgamma, dbeta and the coefficients of dz = ca*dy + cb*z + cc. */
+int trunet_bn_finalize_bwd(const float* partials, int nparts, int C, double count, const float* gamma,
+                           const float* mean, const float* rstd, float* dgamma, float* dbeta, float* ca,
+                           float* cb, float* cc, void* stream);
+
+/* (N,C,L) <-> frames-last [C][L][NP] (zero-fills frames >= N) */
+int trunet_to_frames_last(const float* x_ncl, float* y_clnp, int N, int C, int L, int NP, void* stream);
+int trunet_from_frames_last(const float* x_clnp, float* y_ncl, int N, int C, int L, int NP, void* stream);
+
+/* StandardConv1d forward (network.py:9-21): Conv1d(Cin->Cout,k,s,padding=s/2)+ReLU, frames-last. */
+int trunet_conv_first_fwd(const float* x, const float* w, const float* b, float* y, int Cin, int Cout,
+                          int K, int S, int Lin, int Lout, int NP, void* stream);
+/* (its weight gradient is trunet_conv_wgrad with one segment per tap, pos_mul = stride) */
+
+/* Depthwise Conv1d (network.py:33-38, groups=C, padding=k/2) with BN+ReLU prologue on the input and
+ * statistics of the raw output: partials [nparts][C][2]. */
+int trunet_dwconv_fwd(const float* zin, const float* s_in, const float* t_in, const float* w,
+                      const float* b, float* zout, float* partials, int C, int K, int S, int Lin, int Lout,
+                      int NP, int N, void* stream);
+int trunet_dwconv_nparts(int Lout);
+/* Depthwise backward: dz = ca*dy + cb*z + cc (BN backward of the dw output), then
+ *   g_in = conv_transpose(dz, w) masked by ReLU of the input BN -> dy_in (+ its BN-backward stats),
+ *   dw[c][k], db[c] partials. */
+int trunet_dwconv_bwd(const float* dy, const float* z, const float* ca, const float* cb, const float* cc,
+                      const float* zin, const float* s_in, const float* t_in, const float* mean_in,
+                      const float* w, float* dy_in, float* partials_in, float* w_partials,
+                      float* b_partials, int C, int K, int S, int Lin, int Lout, int NP, int N, void* stream);
+int trunet_dwconv_bwd_nparts(int Lin);
+
+/* Bidirectional GRU recurrence over L positions (nn.GRU, network.py:48,55; torch gate order r,z,n).
+ * gi: [2*3H][L][NP] input projections (+b_ih), hout: [2H][L][NP]; gates (training, may be NULL):
+ * [2][4][H][L][NP] = r, z, n, (W_hn h + b_hn). */
+int trunet_gru_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* w_hh_rev,
+                   const float* b_hh_rev, float* hout, float* gates, int H, int L, int NP, void* stream);
+/* BPTT: dhout [2H][L][NP] -> dgi [2*3H][L][NP], dgh_n [2][H][L][NP] (dgh for r,z equals dgi). */
+int trunet_gru_bwd(const float* dhout, const float* hout, const float* gates, const float* w_hh,
+                   const float* w_hh_rev, float* dgi, float* dghn, int H, int L, int NP, int N,
+                   void* stream);
+
+/* fused AdamW over a flat buffer (torch.optim.AdamW, train.py:68,140) */
+int trunet_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                 float beta2, float eps, float wd, int step, void* stream);
+/* sum of squares -> out[0] (clip_grad_norm_ total norm^2, train.py:138) */
+int trunet_sumsq(const float* g, int64_t n, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,100 @@
+"""GPU parity of the HIP TRU-Net body vs the oracle and the golden vectors (through the C ABI)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def _nets(cin, seed=0):
+    from oracle import network_ref as nr, weights as W
+    from tinyrecurrentunet_amd import network as hn
+    ref = W.fill_state_dict(nr.TRUNet(input_size=cin), seed=seed)
+    net = hn.TRUNet(input_size=cin)
+    net.load_state_dict(ref.state_dict())
+    return ref, net.cuda()
+
+
+@pytest.mark.parametrize("cin", [3, 4])
+def test_forward_matches_golden(golden, cin):
+    """north_star bar: forward within 1e-4 relative fp32 of the reference composition."""
+    g = golden("trunet_cin%d" % cin)
+    _, net = _nets(cin)
+    x = torch.tensor(g["x"]).cuda()
+    net.eval()
+    with torch.no_grad():
+        y = net(x)
+    assert _rel(y, torch.tensor(g["y_eval"])) < 1e-4
+    net.train()
+    y = net(x)
+    assert _rel(y, torch.tensor(g["y_train"])) < 1e-4
+    mse = float(((y.cpu() - torch.tensor(g["y_train"])) ** 2).mean())
+    assert mse < 1e-4
+
+
+@pytest.mark.parametrize("cin", [3, 4])
+def test_backward_matches_golden(golden, cin):
+    g = golden("trunet_cin%d" % cin)
+    _, net = _nets(cin)
+    net.train()
+    y = net(torch.tensor(g["x"]).cuda())
+    (y * torch.tensor(g["cot"]).cuda()).sum().backward()
+    n = 0
+    for pn, p in net.named_parameters():
+        if pn.startswith("TGRU"):
+            assert p.grad is None
+            continue
+        ref = torch.tensor(g["g:" + pn])
+        n += p.numel()
+        # conv biases in front of a BatchNorm have an analytically zero gradient: absolute check only
+        tol = 2e-3 * float(ref.abs().max()) + 2e-4
+        assert float((p.grad.cpu() - ref).abs().max()) < tol, pn
+    assert n == int(g["n_grad_params"])
+    for bn_, b in net.named_buffers():
+        if b.is_floating_point() and not bn_.startswith("TGRU"):
+            assert _rel(b, torch.tensor(g["buf:" + bn_])) < 1e-4, bn_
+
+
+@pytest.mark.parametrize("N", [1, 126, 300])
+def test_forward_backward_vs_oracle_f64(N):
+    """Ragged frame counts (not multiples of the 128-frame tile), vs the fp64 oracle."""
+    from oracle import network_ref as nr, weights as W
+    ref, net = _nets(4, seed=3)
+    refd = W.fill_state_dict(nr.TRUNet(input_size=4), seed=3).double()
+    x = torch.tensor(np.random.default_rng(N).standard_normal((N, 4, 257)) * 0.5, dtype=torch.float32)
+    cot = torch.tensor(np.random.default_rng(N + 1).standard_normal((N, 8, 257)), dtype=torch.float32)
+    refd.eval(); net.eval()
+    with torch.no_grad():
+        assert _rel(net(x.cuda()), refd(x.double())) < 1e-4
+    if N == 1:
+        return    # BatchNorm training statistics need more than one value per channel
+    refd.train(); net.train()
+    yd = refd(x.double()); (yd * cot.double()).sum().backward()
+    y = net(x.cuda()); (y * cot.cuda()).sum().backward()
+    assert _rel(y, yd) < 1e-4
+    pd = dict(refd.named_parameters())
+    for pn, p in net.named_parameters():
+        if pn.startswith("TGRU"):
+            continue
+        ref_g = pd[pn].grad
+        tol = 1e-3 * float(ref_g.abs().max()) + 1e-4
+        assert float((p.grad.double().cpu() - ref_g).abs().max()) < tol, pn
+
+
+def test_state_dict_keys_match_reference_layout():
+    from oracle import network_ref as nr
+    from tinyrecurrentunet_amd import network as hn
+    a, b = nr.TRUNet(3).state_dict(), hn.TRUNet(3).state_dict()
+    assert list(a) == list(b) and len(b) == 177
+    assert all(a[k].shape == b[k].shape for k in a)
+
+
+def test_cpu_tensor_fails_loudly():
+    from tinyrecurrentunet_amd import network as hn, _lib
+    with pytest.raises(_lib.TrunetHipError):
+        hn.TRUNet(3)(torch.zeros(2, 3, 257))

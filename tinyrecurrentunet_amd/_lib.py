@@ -1,0 +1,126 @@
+"""ctypes binding of libtrunet_hip.so (the C ABI declared in include/trunet_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails this raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libtrunet_hip.so")
+
+MAX_SEG = 5
+PRO_NONE, PRO_BNRELU, PRO_BNBWD = 0, 1, 2
+EPI_BIAS, EPI_STATS, EPI_ACCUM, EPI_MASK, EPI_RELU = 1, 2, 4, 8, 16
+
+_fp = C.c_void_p
+
+
+class Seg(C.Structure):
+    _fields_ = [("src0", _fp), ("src1", _fp), ("c0", _fp), ("c1", _fp), ("c2", _fp),
+                ("nchan", C.c_int32), ("L", C.c_int32), ("pos_mul", C.c_int32), ("pos_off", C.c_int32),
+                ("pos_div", C.c_int32), ("woff", C.c_int32), ("mode", C.c_int32), ("_pad", C.c_int32)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("NP", C.c_int32), ("N", C.c_int32), ("P", C.c_int32), ("p_begin", C.c_int32),
+                ("M", C.c_int32), ("m_out_off", C.c_int32), ("out_L", C.c_int32), ("out_pos_off", C.c_int32),
+                ("ldw_m", C.c_int32), ("ldw_c", C.c_int32), ("w_m_off", C.c_int32), ("nseg", C.c_int32),
+                ("epi", C.c_int32), ("M_stat", C.c_int32),
+                ("out", _fp), ("W", _fp), ("bias", _fp), ("zmask", _fp),
+                ("e0", _fp), ("e1", _fp), ("e2", _fp), ("partials", _fp),
+                ("seg", Seg * MAX_SEG)]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [("NP", C.c_int32), ("N", C.c_int32), ("P", C.c_int32), ("p_begin", C.c_int32),
+                ("M", C.c_int32), ("a_L", C.c_int32), ("a_pos_off", C.c_int32), ("a_m_off", C.c_int32),
+                ("a_mode", C.c_int32), ("ldw_m", C.c_int32), ("ldw_c", C.c_int32), ("w_m_off", C.c_int32),
+                ("nseg", C.c_int32), ("w_numel", C.c_int32), ("_pad", C.c_int32),
+                ("a0", _fp), ("a1", _fp), ("ac0", _fp), ("ac1", _fp), ("ac2", _fp),
+                ("w_partials", _fp), ("b_partials", _fp),
+                ("b_stride", C.c_int32), ("b_off", C.c_int32),
+                ("seg", Seg * MAX_SEG)]
+
+
+_lib = None
+
+
+class TrunetHipError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TrunetHipError(
+                "libtrunet_hip.so not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'`; "
+                "there is no CPU fallback for the HIP hot path." % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def _declare(L):
+    i, d, f, p, i64 = C.c_int, C.c_double, C.c_float, _fp, C.c_int64
+    sig = {
+        "trunet_conv_gemm_nparts": [i],
+        "trunet_conv_gemm": [C.POINTER(GemmArgs), p],
+        "trunet_conv_wgrad_nparts": [],
+        "trunet_conv_wgrad": [C.POINTER(WgradArgs), p],
+        "trunet_reduce_partials": [p, p, i, i, i, p],
+        "trunet_bn_finalize_fwd": [p, i, i, d, p, p, f, f, p, p, p, p, p, p, p],
+        "trunet_bn_eval_affine": [i, p, p, p, p, f, p, p, p],
+        "trunet_bn_finalize_bwd": [p, i, i, d, p, p, p, p, p, p, p, p, p],
+        "trunet_to_frames_last": [p, p, i, i, i, i, p],
+        "trunet_from_frames_last": [p, p, i, i, i, i, p],
+        "trunet_conv_first_fwd": [p, p, p, p, i, i, i, i, i, i, i, p],
+        "trunet_dwconv_nparts": [i],
+        "trunet_dwconv_bwd_nparts": [i],
+        "trunet_dwconv_fwd": [p, p, p, p, p, p, p, i, i, i, i, i, i, i, p],
+        "trunet_dwconv_bwd": [p] * 14 + [i] * 7 + [p],
+        "trunet_gru_fwd": [p, p, p, p, p, p, p, i, i, i, p],
+        "trunet_gru_bwd": [p, p, p, p, p, p, p, i, i, i, i, p],
+        "trunet_adamw": [p, p, p, p, i64, f, f, f, f, f, i, p],
+        "trunet_sumsq": [p, i64, p, p],
+    }
+    for name, args in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    L._declared = sorted(sig)
+
+
+def declared_symbols():
+    """Names of every entry point this binding expects (checked against the header in tests)."""
+    return list(lib()._declared)
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise TrunetHipError("libtrunet_hip call failed (%s): code %d" % (what, rc))
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32 torch tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), (t.device, t.dtype, t.is_contiguous())
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def make_seg(src0, nchan, L, pos_mul=1, pos_off=0, pos_div=1, woff=0, mode=PRO_NONE, src1=None, c0=None, c1=None,
+             c2=None):
+    s = Seg()
+    s.src0, s.src1 = ptr(src0), ptr(src1)
+    s.c0, s.c1, s.c2 = ptr(c0), ptr(c1), ptr(c2)
+    s.nchan, s.L = nchan, L
+    s.pos_mul, s.pos_off, s.pos_div = pos_mul, pos_off, pos_div
+    s.woff, s.mode = woff, mode
+    return s

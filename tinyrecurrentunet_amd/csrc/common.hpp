@@ -1,0 +1,45 @@
+// Shared device/host helpers for libtrunet_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "trunet_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define TRUNET_NUM_CU 256
+
+static inline int trunet_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? TRUNET_OK : TRUNET_ELAUNCH;
+}
+
+// sum over the 32 lanes that share (lane >> 5)
+__device__ __forceinline__ float half_wave_sum(float v) {
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 1);
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+    v += __shfl_xor(v, 32);
+    return half_wave_sum(v);
+}
+
+// block-wide sum for 256-thread blocks; result valid in thread 0 (and broadcast through smem[0])
+__device__ __forceinline__ double block_sum_f64(double v, double* smem /* >= 256 */) {
+    int t = threadIdx.x;
+    smem[t] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) smem[t] += smem[t + s];
+        __syncthreads();
+    }
+    double r = smem[0];
+    __syncthreads();
+    return r;
+}

@@ -1,0 +1,375 @@
+// Memory-bound stages of the TRU-Net body in the frames-last layout: layout changes, the first
+// (C_in -> 64) strided conv, depthwise convs (forward / backward), BatchNorm statistics -> affine,
+// AdamW.  All are HBM-bound: coalesced 16-byte accesses along the frame axis, one pass per tensor.
+#include "common.hpp"
+
+namespace {
+
+// ---------------------------------------------------------------- layout changes
+// X[N][R] (R = C*L contiguous per frame)  <->  Y[R][NP]
+__global__ void to_frames_last_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int R, int NP) {
+    __shared__ float t[32][33];
+    const int n0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x, ty = threadIdx.y;  // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        int n = n0 + i, r = r0 + tx;
+        t[i][tx] = (n < N && r < R) ? x[(size_t)n * R + r] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        int r = r0 + i, n = n0 + tx;
+        if (r < R && n < NP) y[(size_t)r * NP + n] = t[tx][i];
+    }
+}
+
+__global__ void from_frames_last_kernel(const float* __restrict__ y, float* __restrict__ x, int N, int R, int NP) {
+    __shared__ float t[32][33];
+    const int n0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    for (int i = ty; i < 32; i += 8) {
+        int r = r0 + i, n = n0 + tx;
+        t[i][tx] = (r < R && n < NP) ? y[(size_t)r * NP + n] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        int n = n0 + i, r = r0 + tx;
+        if (n < N && r < R) x[(size_t)n * R + r] = t[tx][i];
+    }
+}
+
+// ---------------------------------------------------------------- first conv (+ReLU)
+// y[co][lo][n] = relu(b[co] + sum_{ci,k} w[co][ci][k] * x[ci][lo*S + k - S/2][n])
+template <int CIN, int K>
+__global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ b, float* __restrict__ y, int Cout,
+                                                         int S, int Lin, int Lout, int NP) {
+    const int f4 = threadIdx.x;                 // 32 lanes x float4 = 128 frames
+    const int lo = blockIdx.y * 8 + threadIdx.y;
+    const size_t n = (size_t)blockIdx.x * 128 + 4 * f4;
+    if (lo >= Lout) return;
+    f32x4 xv[CIN][K];
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            int li = lo * S + k - S / 2;
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            xv[ci][k] = (li >= 0 && li < Lin) ? *(const f32x4*)(x + ((size_t)ci * Lin + li) * NP + n) : z;
+        }
+    for (int co = 0; co < Cout; ++co) {
+        const float bb = b[co];
+        f32x4 acc = {bb, bb, bb, bb};
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float wv = w[(co * CIN + ci) * K + k];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = fmaf(wv, xv[ci][k][e], acc[e]);
+            }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e], 0.f);
+        *(f32x4*)(y + ((size_t)co * Lout + lo) * NP + n) = acc;
+    }
+}
+
+// ---------------------------------------------------------------- depthwise conv forward
+constexpr int DW_PARTS = 16;
+
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict__ zin, const float* __restrict__ s_in,
+                                                         const float* __restrict__ t_in, const float* __restrict__ w,
+                                                         const float* __restrict__ b, float* __restrict__ zout,
+                                                         float* __restrict__ partials, int C, int S, int Lin, int Lout,
+                                                         int NP, int N) {
+    __shared__ double red[256];
+    const int c = blockIdx.y;
+    const int f4 = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const float sc = s_in[c], sh = t_in[c], bb = b[c];
+    float wk[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) wk[k] = w[c * K + k];
+    const int ntn = NP / 128;
+    const int items = Lout * ntn;
+    float s1 = 0.f, s2 = 0.f;
+    for (int it = blockIdx.x * 8 + ly; it < items; it += gridDim.x * 8) {
+        const int nt = it / Lout, lo = it - nt * Lout;
+        const int n = nt * 128 + 4 * f4;
+        f32x4 acc = {bb, bb, bb, bb};
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int li = lo * S + k - K / 2;
+            if (li >= 0 && li < Lin) {
+                f32x4 v = *(const f32x4*)(zin + ((size_t)c * Lin + li) * NP + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = fmaf(wk[k], fmaxf(fmaf(v[e], sc, sh), 0.f), acc[e]);
+            }
+        }
+        *(f32x4*)(zout + ((size_t)c * Lout + lo) * NP + n) = acc;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (n + e < N) { s1 += acc[e]; s2 = fmaf(acc[e], acc[e], s2); }
+    }
+    double r1 = block_sum_f64((double)s1, red);
+    double r2 = block_sum_f64((double)s2, red);
+    if (threadIdx.x == 0) {
+        partials[((size_t)blockIdx.x * C + c) * 2 + 0] = (float)r1;
+        partials[((size_t)blockIdx.x * C + c) * 2 + 1] = (float)r2;
+    }
+}
+
+// ---------------------------------------------------------------- depthwise conv backward
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_bwd_kernel(
+    const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ ca,
+    const float* __restrict__ cb, const float* __restrict__ cc, const float* __restrict__ zin,
+    const float* __restrict__ s_in, const float* __restrict__ t_in, const float* __restrict__ mean_in,
+    const float* __restrict__ w, float* __restrict__ dy_in, float* __restrict__ partials_in,
+    float* __restrict__ w_partials, float* __restrict__ b_partials, int C, int S, int Lin, int Lout, int NP, int N) {
+    __shared__ double red[256];
+    const int c = blockIdx.y;
+    const int f4 = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const float a0 = ca[c], a1 = cb[c], a2 = cc[c];
+    const float sc = s_in[c], sh = t_in[c], mu = mean_in[c];
+    float wk[K], dwk[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { wk[k] = w[c * K + k]; dwk[k] = 0.f; }
+    float db = 0.f, s1 = 0.f, s2 = 0.f;
+    const int ntn = NP / 128;
+    const int items = Lin * ntn;
+    for (int it = blockIdx.x * 8 + ly; it < items; it += gridDim.x * 8) {
+        const int nt = it / Lin, li = it - nt * Lin;
+        const int n = nt * 128 + 4 * f4;
+        const f32x4 zi = *(const f32x4*)(zin + ((size_t)c * Lin + li) * NP + n);
+        f32x4 act, g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) act[e] = fmaxf(fmaf(zi[e], sc, sh), 0.f);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int num = li + K / 2 - k;
+            const int lo = num / S;
+            if (num >= 0 && lo * S == num && lo < Lout) {
+                const size_t off = ((size_t)c * Lout + lo) * NP + n;
+                const f32x4 dv = *(const f32x4*)(dy + off);
+                const f32x4 zv = *(const f32x4*)(z + off);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float dz = (n + e < N) ? fmaf(a0, dv[e], fmaf(a1, zv[e], a2)) : 0.f;
+                    g[e] = fmaf(wk[k], dz, g[e]);
+                    dwk[k] = fmaf(dz, act[e], dwk[k]);
+                    if (k == K / 2) db += dz;
+                }
+            }
+        }
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e] = (act[e] > 0.f) ? g[e] : 0.f;
+            s1 += o[e];
+            s2 = fmaf(o[e], zi[e] - mu, s2);
+        }
+        *(f32x4*)(dy_in + ((size_t)c * Lin + li) * NP + n) = o;
+    }
+    double r;
+    r = block_sum_f64((double)s1, red);
+    if (threadIdx.x == 0) partials_in[((size_t)blockIdx.x * C + c) * 2 + 0] = (float)r;
+    r = block_sum_f64((double)s2, red);
+    if (threadIdx.x == 0) partials_in[((size_t)blockIdx.x * C + c) * 2 + 1] = (float)r;
+    r = block_sum_f64((double)db, red);
+    if (threadIdx.x == 0) b_partials[(size_t)blockIdx.x * C + c] = (float)r;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        r = block_sum_f64((double)dwk[k], red);
+        if (threadIdx.x == 0) w_partials[((size_t)blockIdx.x * C + c) * K + k] = (float)r;
+    }
+}
+
+// ---------------------------------------------------------------- BatchNorm statistics -> affine
+__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __restrict__ partials, int nparts, int C,
+                                                              double count, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps, float momentum,
+                                                              float* running_mean, float* running_var, float* scale,
+                                                              float* shift, float* mean_o, float* rstd_o) {
+    __shared__ double red[256];
+    const int c = blockIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int g = threadIdx.x; g < nparts; g += 256) {
+        a += (double)partials[((size_t)g * C + c) * 2 + 0];
+        b += (double)partials[((size_t)g * C + c) * 2 + 1];
+    }
+    a = block_sum_f64(a, red);
+    b = block_sum_f64(b, red);
+    if (threadIdx.x == 0) {
+        double mean = a / count;
+        double var = b / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        float sc = gamma[c] * rstd;
+        scale[c] = sc;
+        shift[c] = beta[c] - (float)mean * sc;
+        mean_o[c] = (float)mean;
+        rstd_o[c] = rstd;
+        if (running_mean) {
+            double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+        }
+    }
+}
+
+__global__ void bn_eval_affine_kernel(int C, const float* gamma, const float* beta, const float* rm, const float* rv,
+                                      float eps, float* scale, float* shift) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float sc = gamma[c] / sqrtf(rv[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __restrict__ partials, int nparts, int C,
+                                                              double count, const float* __restrict__ gamma,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              float* dgamma, float* dbeta, float* ca, float* cb, float* cc) {
+    __shared__ double red[256];
+    const int c = blockIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int g = threadIdx.x; g < nparts; g += 256) {
+        a += (double)partials[((size_t)g * C + c) * 2 + 0];
+        b += (double)partials[((size_t)g * C + c) * 2 + 1];
+    }
+    a = block_sum_f64(a, red);   // sum dy
+    b = block_sum_f64(b, red);   // sum dy*(z-mean)
+    if (threadIdx.x == 0) {
+        const double r = rstd[c], g = gamma[c], mu = mean[c];
+        const double m1 = a / count;             // mean(dy)
+        const double m2 = r * b / count;         // mean(dy*xhat)
+        dgamma[c] = (float)(r * b);
+        dbeta[c] = (float)a;
+        ca[c] = (float)(g * r);
+        cb[c] = (float)(-g * r * r * m2);
+        cc[c] = (float)(-g * r * m1 + g * r * r * m2 * mu);
+    }
+}
+
+// ---------------------------------------------------------------- optimizer
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                             float bc1, float bc2_sqrt) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float gi = g[i];
+    float pi = p[i] * (1.f - lr * wd);
+    float mi = b1 * m[i] + (1.f - b1) * gi;
+    float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += (double)g[i] * (double)g[i];
+    s = block_sum_f64(s, red);
+    if (threadIdx.x == 0) out[0] = (float)s;
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int trunet_to_frames_last(const float* x, float* y, int N, int C, int L, int NP, void* stream) {
+    if (!x || !y || N <= 0 || NP < N) return TRUNET_EINVAL;
+    int R = C * L;
+    hipLaunchKernelGGL(to_frames_last_kernel, dim3((NP + 31) / 32, (R + 31) / 32), dim3(32, 8), 0, ST, x, y, N, R, NP);
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_from_frames_last(const float* x, float* y, int N, int C, int L, int NP, void* stream) {
+    if (!x || !y || N <= 0 || NP < N) return TRUNET_EINVAL;
+    int R = C * L;
+    hipLaunchKernelGGL(from_frames_last_kernel, dim3((NP + 31) / 32, (R + 31) / 32), dim3(32, 8), 0, ST, x, y, N, R, NP);
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_conv_first_fwd(const float* x, const float* w, const float* b, float* y, int Cin, int Cout, int K,
+                                     int S, int Lin, int Lout, int NP, void* stream) {
+    if (!x || !w || !b || !y || (NP % 128)) return TRUNET_EINVAL;
+    dim3 grid(NP / 128, (Lout + 7) / 8), block(32, 8);
+    if (K == 5 && Cin == 3) hipLaunchKernelGGL((conv_first_kernel<3, 5>), grid, block, 0, ST, x, w, b, y, Cout, S, Lin, Lout, NP);
+    else if (K == 5 && Cin == 4) hipLaunchKernelGGL((conv_first_kernel<4, 5>), grid, block, 0, ST, x, w, b, y, Cout, S, Lin, Lout, NP);
+    else return TRUNET_ENOTSUP;
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_dwconv_nparts(int Lout) { (void)Lout; return DW_PARTS; }
+extern "C" int trunet_dwconv_bwd_nparts(int Lin) { (void)Lin; return DW_PARTS; }
+
+extern "C" int trunet_dwconv_fwd(const float* zin, const float* s_in, const float* t_in, const float* w, const float* b,
+                                 float* zout, float* partials, int C, int K, int S, int Lin, int Lout, int NP, int N,
+                                 void* stream) {
+    if (!zin || !s_in || !t_in || !w || !b || !zout || !partials || (NP % 128)) return TRUNET_EINVAL;
+    dim3 grid(DW_PARTS, C);
+    if (K == 3) hipLaunchKernelGGL(dwconv_fwd_kernel<3>, grid, dim3(256), 0, ST, zin, s_in, t_in, w, b, zout, partials, C, S, Lin, Lout, NP, N);
+    else if (K == 5) hipLaunchKernelGGL(dwconv_fwd_kernel<5>, grid, dim3(256), 0, ST, zin, s_in, t_in, w, b, zout, partials, C, S, Lin, Lout, NP, N);
+    else return TRUNET_ENOTSUP;
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_dwconv_bwd(const float* dy, const float* z, const float* ca, const float* cb, const float* cc,
+                                 const float* zin, const float* s_in, const float* t_in, const float* mean_in,
+                                 const float* w, float* dy_in, float* partials_in, float* w_partials, float* b_partials,
+                                 int C, int K, int S, int Lin, int Lout, int NP, int N, void* stream) {
+    if (!dy || !z || !ca || !cb || !cc || !zin || !s_in || !t_in || !mean_in || !w || !dy_in || !partials_in ||
+        !w_partials || !b_partials || (NP % 128))
+        return TRUNET_EINVAL;
+    dim3 grid(DW_PARTS, C);
+    if (K == 3) hipLaunchKernelGGL(dwconv_bwd_kernel<3>, grid, dim3(256), 0, ST, dy, z, ca, cb, cc, zin, s_in, t_in, mean_in, w, dy_in, partials_in, w_partials, b_partials, C, S, Lin, Lout, NP, N);
+    else if (K == 5) hipLaunchKernelGGL(dwconv_bwd_kernel<5>, grid, dim3(256), 0, ST, dy, z, ca, cb, cc, zin, s_in, t_in, mean_in, w, dy_in, partials_in, w_partials, b_partials, C, S, Lin, Lout, NP, N);
+    else return TRUNET_ENOTSUP;
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_bn_finalize_fwd(const float* partials, int nparts, int C, double count, const float* gamma,
+                                      const float* beta, float eps, float momentum, float* running_mean,
+                                      float* running_var, float* scale, float* shift, float* mean, float* rstd,
+                                      void* stream) {
+    if (!partials || !gamma || !beta || !scale || !shift || !mean || !rstd || C <= 0 || nparts <= 0) return TRUNET_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(C), dim3(256), 0, ST, partials, nparts, C, count, gamma, beta, eps,
+                       momentum, running_mean, running_var, scale, shift, mean, rstd);
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean,
+                                     const float* running_var, float eps, float* scale, float* shift, void* stream) {
+    if (!gamma || !beta || !running_mean || !running_var || !scale || !shift) return TRUNET_EINVAL;
+    hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 127) / 128), dim3(128), 0, ST, C, gamma, beta, running_mean,
+                       running_var, eps, scale, shift);
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_bn_finalize_bwd(const float* partials, int nparts, int C, double count, const float* gamma,
+                                      const float* mean, const float* rstd, float* dgamma, float* dbeta, float* ca,
+                                      float* cb, float* cc, void* stream) {
+    if (!partials || !gamma || !mean || !rstd || !dgamma || !dbeta || !ca || !cb || !cc) return TRUNET_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(C), dim3(256), 0, ST, partials, nparts, C, count, gamma, mean, rstd,
+                       dgamma, dbeta, ca, cb, cc);
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                            float eps, float wd, int step, void* stream) {
+    if (!p || !g || !m || !v || n <= 0 || step < 1) return TRUNET_EINVAL;
+    float bc1 = 1.f - powf(beta1, (float)step);
+    float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ST, p, g, m, v, n, lr, beta1, beta2,
+                       eps, wd, bc1, bc2s);
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_sumsq(const float* g, int64_t n, float* out, void* stream) {
+    if (!g || !out || n <= 0) return TRUNET_EINVAL;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(256), 0, ST, g, n, out);
+    return trunet_launch_status();
+}

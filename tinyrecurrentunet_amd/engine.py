@@ -1,0 +1,493 @@
+"""Host-side schedule of the TRU-Net body on the HIP kernels (frames-last layout).
+
+This is the MI355X-native replacement for what ATen does behind ``TRUNet.forward`` /
+``loss.backward()`` in the reference (``/root/reference/network.py:122-171`` with repairs R1-R4
+of SURVEY.md section 0.2).  Every tensor between layers is the RAW conv output (pre-BatchNorm);
+BatchNorm+ReLU is applied by the consumer while it stages its operand, BatchNorm statistics
+come from the producer's epilogue, and ``F.pad``/``torch.cat`` of the decoder are just row
+offsets / a second operand segment -- nothing is copied.  Backward mirrors this: one dgrad launch
+produces dy (ReLU-masked) plus the BatchNorm-backward sums, one wgrad launch per weight.
+
+PyTorch is used for device memory only; all arithmetic is in libtrunet_hip.so.
+"""
+import torch
+
+from . import _lib as L
+from ._lib import (EPI_ACCUM, EPI_BIAS, EPI_MASK, EPI_STATS, PRO_BNBWD, PRO_BNRELU, PRO_NONE, GemmArgs,
+                   WgradArgs, check, make_seg, ptr)
+
+F_BINS = 257
+BN_EPS = 1e-5
+BN_MOM = 0.1
+
+
+def ceil_to(n, m):
+    return (n + m - 1) // m * m
+
+
+class BNState:
+    """Per-layer BatchNorm affine (forward) and backward coefficients, all [C] device tensors."""
+
+    def __init__(self, C, dev):
+        z = lambda: torch.empty(C, device=dev, dtype=torch.float32)
+        self.C = C
+        self.scale, self.shift, self.mean, self.rstd = z(), z(), z(), z()
+        self.ca, self.cb, self.cc = z(), z(), z()
+        self.dgamma, self.dbeta = z(), z()
+        self.count = 0.0
+        self.module = None
+
+
+class Act:
+    """A frames-last activation [C][L][NP] and how a consumer must read it."""
+
+    def __init__(self, t, C, Ln, bn=None):
+        self.t, self.C, self.L, self.bn = t, C, Ln, bn
+
+    def seg(self, pos_off=0, woff=0, pos_mul=1, pos_div=1):
+        if self.bn is None:
+            return make_seg(self.t, self.C, self.L, pos_mul, pos_off, pos_div, woff, PRO_NONE)
+        return make_seg(self.t, self.C, self.L, pos_mul, pos_off, pos_div, woff, PRO_BNRELU,
+                        c0=self.bn.scale, c1=self.bn.shift)
+
+
+class Workspace:
+    def __init__(self, dev):
+        self.dev = dev
+        self.t = {}
+
+    def get(self, name, shape, zero=False):
+        t = self.t.get(name)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = (torch.zeros if zero else torch.empty)(shape, device=self.dev, dtype=torch.float32)
+            self.t[name] = t
+        elif zero:
+            t.zero_()
+        return t
+
+    def flat(self, name, numel):
+        """Grow-only 1-D scratch buffer (stream order makes sharing between layers safe)."""
+        t = self.t.get(name)
+        if t is None or t.numel() < numel:
+            t = torch.empty(max(numel, 1), device=self.dev, dtype=torch.float32)
+            self.t[name] = t
+        return t
+
+    def bn(self, name, C):
+        b = self.t.get("bn:" + name)
+        if b is None:
+            b = BNState(C, self.dev)
+            self.t["bn:" + name] = b
+        return b
+
+
+class TRUNetEngine:
+    # (kernel, stride) of the depthwise convs of encoder.1..5 and of the transposed convs of decoder.0..5
+    ENC = [(3, 1), (5, 2), (3, 1), (5, 2), (3, 2)]
+    DEC = [(3, 2), (5, 2), (3, 1), (5, 2), (3, 1), (5, 2)]
+
+    def __init__(self, net):
+        self.net = net
+        self._ws = {}
+
+    # ------------------------------------------------------------------ helpers
+    def ws(self, NP, dev):
+        key = (NP, str(dev))
+        if key not in self._ws:
+            self._ws = {key: Workspace(dev)}      # keep one size resident
+        return self._ws[key]
+
+    def _gemm(self, w, *, N, NP, P, M, out, out_L, W, ldw_m, ldw_c, segs, p_begin=0, out_pos_off=0, m_out_off=0,
+              w_m_off=0, epi=0, bias=None, zmask=None, e0=None, e1=None, e2=None, stats=None):
+        a = GemmArgs()
+        a.NP, a.N, a.P, a.p_begin = NP, N, P, p_begin
+        a.M, a.m_out_off, a.out_L, a.out_pos_off = M, m_out_off, out_L, out_pos_off
+        a.ldw_m, a.ldw_c, a.w_m_off = ldw_m, ldw_c, w_m_off
+        a.nseg = len(segs)
+        for i, s in enumerate(segs):
+            a.seg[i] = s
+        a.out, a.W = ptr(out), ptr(W)
+        if bias is not None:
+            epi |= EPI_BIAS
+            a.bias = ptr(bias)
+        if zmask is not None:
+            epi |= EPI_MASK
+            a.zmask, a.e0, a.e1, a.e2 = ptr(zmask), ptr(e0), ptr(e1), ptr(e2)
+        nparts = 0
+        if stats is not None:
+            epi |= EPI_STATS
+            nparts = L.lib().trunet_conv_gemm_nparts(M)
+            part = w.flat("partials", nparts * stats * 2)
+            a.partials, a.M_stat = ptr(part), stats
+        a.epi = epi
+        check(L.lib().trunet_conv_gemm(a, L.stream()), "conv_gemm")
+        return nparts
+
+    def _bn_fwd(self, w, name, module, C, count, nparts, training):
+        st = w.bn(name, C)
+        st.module, st.count = module, float(count)
+        lib = L.lib()
+        if training:
+            part = w.flat("partials", nparts * C * 2)
+            rm = module.running_mean if module.track_running_stats else None
+            rv = module.running_var if module.track_running_stats else None
+            mom = BN_MOM if module.momentum is None else module.momentum
+            check(lib.trunet_bn_finalize_fwd(ptr(part), nparts, C, float(count), ptr(module.weight.data),
+                                             ptr(module.bias.data), module.eps, mom, ptr(rm), ptr(rv),
+                                             ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.rstd), L.stream()),
+                  "bn_finalize_fwd")
+            if module.track_running_stats:
+                module.num_batches_tracked.add_(1)
+        else:
+            check(lib.trunet_bn_eval_affine(C, ptr(module.weight.data), ptr(module.bias.data),
+                                            ptr(module.running_mean), ptr(module.running_var), module.eps,
+                                            ptr(st.scale), ptr(st.shift), L.stream()), "bn_eval_affine")
+        return st
+
+    def _pw(self, w, name, srcs, conv, bn, N, NP, training, x1_left=0):
+        """Conv1d(k=1) over one or two concatenated sources (+BN statistics).  srcs[0] may be
+        shorter/longer than the output length (F.pad / crop by ``x1_left``, network.py:96-98)."""
+        Ln = srcs[-1].L
+        Co = conv.out_channels
+        K = conv.in_channels
+        out = w.get("z:" + name, (Co, Ln, NP))
+        segs, off = [], 0
+        for i, s in enumerate(srcs):
+            segs.append(s.seg(pos_off=(-x1_left if (i == 0 and len(srcs) == 2) else 0), woff=off))
+            off += s.C
+        assert off == K
+        nparts = self._gemm(w, N=N, NP=NP, P=Ln, M=Co, out=out, out_L=Ln, W=conv.weight.data, ldw_m=K, ldw_c=1,
+                            segs=segs, bias=conv.bias.data, stats=(Co if (bn is not None and training) else None))
+        st = self._bn_fwd(w, name, bn, Co, N * Ln, nparts, training) if bn is not None else None
+        return Act(out, Co, Ln, st)
+
+    def _convT(self, w, name, src, conv, bn, N, NP, training):
+        k, s = conv.kernel_size[0], conv.stride[0]
+        pad = conv.padding[0]
+        Ci, Co = conv.in_channels, conv.out_channels
+        Lo = (src.L - 1) * s - 2 * pad + k
+        out = w.get("z:" + name, (Co, Lo, NP))
+        segs = [src.seg(pos_off=pad - kk, woff=kk, pos_div=s) for kk in range(k)]
+        nparts = self._gemm(w, N=N, NP=NP, P=Lo, M=Co, out=out, out_L=Lo, W=conv.weight.data, ldw_m=k,
+                            ldw_c=Co * k, segs=segs, bias=conv.bias.data,
+                            stats=(Co if (bn is not None and training) else None))
+        st = self._bn_fwd(w, name, bn, Co, N * Lo, nparts, training) if bn is not None else None
+        return Act(out, Co, Lo, st)
+
+    def _dw(self, w, name, src, conv, bn, N, NP, training):
+        k, s = conv.kernel_size[0], conv.stride[0]
+        C = conv.out_channels
+        Lo = (src.L + 2 * (k // 2) - k) // s + 1
+        out = w.get("z:" + name, (C, Lo, NP))
+        lib = L.lib()
+        nparts = lib.trunet_dwconv_nparts(Lo)
+        part = w.flat("partials_dw", nparts * C * 2)
+        check(lib.trunet_dwconv_fwd(ptr(src.t), ptr(src.bn.scale), ptr(src.bn.shift), ptr(conv.weight.data),
+                                    ptr(conv.bias.data), ptr(out), ptr(part), C, k, s, src.L, Lo, NP, N,
+                                    L.stream()), "dwconv_fwd")
+        st = w.bn(name, C)
+        st.module, st.count = bn, float(N * Lo)
+        if training:
+            rm = bn.running_mean if bn.track_running_stats else None
+            rv = bn.running_var if bn.track_running_stats else None
+            mom = BN_MOM if bn.momentum is None else bn.momentum
+            check(lib.trunet_bn_finalize_fwd(ptr(part), nparts, C, float(N * Lo), ptr(bn.weight.data),
+                                             ptr(bn.bias.data), bn.eps, mom, ptr(rm), ptr(rv), ptr(st.scale),
+                                             ptr(st.shift), ptr(st.mean), ptr(st.rstd), L.stream()), "bn_finalize_fwd")
+            if bn.track_running_stats:
+                bn.num_batches_tracked.add_(1)
+        else:
+            check(lib.trunet_bn_eval_affine(C, ptr(bn.weight.data), ptr(bn.bias.data), ptr(bn.running_mean),
+                                            ptr(bn.running_var), bn.eps, ptr(st.scale), ptr(st.shift), L.stream()),
+                  "bn_eval_affine")
+        return Act(out, C, Lo, st)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, training):
+        net = self.net
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[2] == F_BINS
+        x = x.contiguous()
+        N, Cin = x.shape[0], x.shape[1]
+        NP = ceil_to(N, 128)
+        w = self.ws(NP, x.device)
+        lib = L.lib()
+        st = L.stream()
+        acts = {}
+
+        xt = w.get("x", (Cin, F_BINS, NP))
+        check(lib.trunet_to_frames_last(ptr(x), ptr(xt), N, Cin, F_BINS, NP, st), "to_frames_last")
+        c0 = net.encoder[0].StandardConv1d[0]
+        assert c0.in_channels == Cin
+        a0t = w.get("z:enc0", (64, 128, NP))
+        check(lib.trunet_conv_first_fwd(ptr(xt), ptr(c0.weight.data), ptr(c0.bias.data), ptr(a0t), Cin, 64,
+                                        c0.kernel_size[0], c0.stride[0], F_BINS, 128, NP, st), "conv_first_fwd")
+        acts["x"] = Act(xt, Cin, F_BINS)
+        cur = acts["enc0"] = Act(a0t, 64, 128)
+        for i in range(1, 6):
+            seq = net.encoder[i].DepthwiseSeparableConv1d
+            cur = acts["enc%d.pw" % i] = self._pw(w, "enc%d.pw" % i, [cur], seq[0], seq[1], N, NP, training)
+            cur = acts["enc%d" % i] = self._dw(w, "enc%d" % i, cur, seq[3], seq[4], N, NP, training)
+
+        # FGRU: input projection (both directions, M = 384), recurrence, pw conv + BN
+        gru = net.FGRU.GRU
+        Hh = gru.hidden_size
+        wih = w.get("wih", (6 * Hh, gru.input_size))
+        bih = w.get("bih", (6 * Hh,))
+        torch.cat((gru.weight_ih_l0.data, gru.weight_ih_l0_reverse.data), 0, out=wih)
+        torch.cat((gru.bias_ih_l0.data, gru.bias_ih_l0_reverse.data), 0, out=bih)
+        Lg = cur.L
+        gi = w.get("gi", (6 * Hh, Lg, NP))
+        self._gemm(w, N=N, NP=NP, P=Lg, M=6 * Hh, out=gi, out_L=Lg, W=wih, ldw_m=gru.input_size, ldw_c=1,
+                   segs=[cur.seg()], bias=bih)
+        hout = w.get("hout", (2 * Hh, Lg, NP))
+        gates = w.get("gates", (2, 4, Hh, Lg, NP)) if training else None
+        check(lib.trunet_gru_fwd(ptr(gi), ptr(gru.weight_hh_l0.data), ptr(gru.bias_hh_l0.data),
+                                 ptr(gru.weight_hh_l0_reverse.data), ptr(gru.bias_hh_l0_reverse.data), ptr(hout),
+                                 ptr(gates), Hh, Lg, NP, st), "gru_fwd")
+        acts["hout"] = Act(hout, 2 * Hh, Lg)
+        cur = acts["fgru"] = self._pw(w, "fgru", [acts["hout"]], net.FGRU.conv[0], net.FGRU.conv[1], N, NP, training)
+
+        seq = net.decoder[0].FirstTrCNN
+        cur = acts["dec0.pw"] = self._pw(w, "dec0.pw", [cur], seq[0], seq[1], N, NP, training)
+        cur = acts["dec0"] = self._convT(w, "dec0", cur, seq[3], seq[4], N, NP, training)
+        for i in range(1, 6):
+            skip = acts["enc%d" % (5 - i)]
+            seq = net.decoder[i].TrCNN if i < 5 else net.decoder[i].LastTrCNN
+            left = (skip.L - cur.L) // 2                       # F.pad left amount (negative = crop)
+            cur = acts["dec%d.pw" % i] = self._pw(w, "dec%d.pw" % i, [cur, skip], seq[0], seq[1], N, NP, training,
+                                                  x1_left=left)
+            cur = acts["dec%d" % i] = self._convT(w, "dec%d" % i, cur, seq[3], seq[4] if i < 5 else None, N, NP,
+                                                  training)
+        out = torch.empty((N, cur.C, cur.L), device=x.device, dtype=torch.float32)
+        check(lib.trunet_from_frames_last(ptr(cur.t), ptr(out), N, cur.C, cur.L, NP, st), "from_frames_last")
+        return out, (acts, N, NP, w)
+
+    # ------------------------------------------------------------------ backward
+    def _bn_bwd(self, w, st, nparts, grads, part_name="partials"):
+        m = st.module
+        part = w.flat(part_name, nparts * st.C * 2)
+        check(L.lib().trunet_bn_finalize_bwd(ptr(part), nparts, st.C, st.count, ptr(m.weight.data), ptr(st.mean),
+                                             ptr(st.rstd), ptr(st.dgamma), ptr(st.dbeta), ptr(st.ca), ptr(st.cb),
+                                             ptr(st.cc), L.stream()), "bn_finalize_bwd")
+        grads[m.weight] = st.dgamma.clone()
+        grads[m.bias] = st.dbeta.clone()
+
+    def _wgrad(self, w, *, N, NP, P, M, dz, dz_L, dz_bn, W, ldw_m, ldw_c, segs, grads, bias=None, a_pos_off=0,
+               a_m_off=0, w_m_off=0, reduce=True, b_total=None, b_off=0, wgrad_out=None, bgrad_out=None, dz1=None):
+        lib = L.lib()
+        nparts = lib.trunet_conv_wgrad_nparts()
+        numel = W.numel()
+        a = WgradArgs()
+        a.NP, a.N, a.P, a.p_begin = NP, N, P, 0
+        a.M, a.a_L, a.a_pos_off, a.a_m_off = M, dz_L, a_pos_off, a_m_off
+        a.ldw_m, a.ldw_c, a.w_m_off = ldw_m, ldw_c, w_m_off
+        a.nseg = len(segs)
+        for i, s in enumerate(segs):
+            a.seg[i] = s
+        a.w_numel = numel
+        a.a0 = ptr(dz)
+        if dz_bn is not None:
+            a.a_mode = PRO_BNBWD
+            a.a1, a.ac0, a.ac1, a.ac2 = ptr(dz1), ptr(dz_bn.ca), ptr(dz_bn.cb), ptr(dz_bn.cc)
+        else:
+            a.a_mode = PRO_NONE
+        wp = w.flat("w_partials", nparts * 32768)
+        a.w_partials = ptr(wp)
+        bt = b_total if b_total is not None else M
+        bp = w.flat("b_partials", nparts * 512)
+        a.b_partials = ptr(bp)
+        a.b_stride, a.b_off = bt, b_off
+        check(lib.trunet_conv_wgrad(a, L.stream()), "conv_wgrad")
+        if reduce:
+            gw = wgrad_out if wgrad_out is not None else torch.empty_like(W)
+            check(lib.trunet_reduce_partials(ptr(gw), ptr(wp), nparts, numel, 0, L.stream()), "reduce")
+            gb = bgrad_out if bgrad_out is not None else torch.empty(bt, device=W.device, dtype=torch.float32)
+            check(lib.trunet_reduce_partials(ptr(gb), ptr(bp), nparts, bt, 0, L.stream()), "reduce")
+            if wgrad_out is None:
+                grads[W] = gw
+            if bias is not None and bgrad_out is None:
+                grads[bias] = gb
+            return gw, gb
+        return None
+
+    def backward(self, ctx, gout):
+        """gout: (N, 8, 257) cotangent.  Returns {parameter tensor: gradient}."""
+        acts, N, NP, w = ctx
+        net = self.net
+        lib = L.lib()
+        st = L.stream()
+        grads = {}
+        gout = gout.contiguous()
+        last = acts["dec5"]
+        dyt = w.get("dy:dec5", (last.C, last.L, NP))
+        check(lib.trunet_to_frames_last(ptr(gout), ptr(dyt), N, last.C, last.L, NP, st), "to_frames_last")
+
+        # current upstream gradient: (dy tensor, z tensor, BN state of that z or None)
+        dy, z, bn = dyt, last.t, None
+
+        def dz_segs(dy_, z_, bn_, C, Ln, **kw):
+            if bn_ is None:
+                return make_seg(dy_, C, Ln, mode=PRO_NONE, **kw)
+            return make_seg(dy_, C, Ln, mode=PRO_BNBWD, src1=z_, c0=bn_.ca, c1=bn_.cb, c2=bn_.cc, **kw)
+
+        # -------- decoder, last to first
+        for i in range(5, -1, -1):
+            seq = (net.decoder[i].LastTrCNN if i == 5 else net.decoder[i].TrCNN) if i > 0 else net.decoder[0].FirstTrCNN
+            ct, pw = seq[3], seq[0]
+            k, s_, pad = ct.kernel_size[0], ct.stride[0], ct.padding[0]
+            Ci, Co = ct.in_channels, ct.out_channels
+            a_pw = acts["dec%d.pw" % i]           # input of the transposed conv (raw pw output + BN)
+            Lo = acts["dec%d" % i].L
+            # transposed conv: weight/bias gradient
+            self._wgrad(w, N=N, NP=NP, P=Lo, M=Co, dz=dy, dz1=z, dz_L=Lo, dz_bn=bn, W=ct.weight, ldw_m=k,
+                        ldw_c=Co * k, segs=[a_pw.seg(pos_off=pad - kk, woff=kk, pos_div=s_) for kk in range(k)],
+                        grads=grads, bias=ct.bias)
+            # transposed conv: data gradient -> dy of the pw BN (+ stats)
+            dy_pw = w.get("dy:dec%d.pw" % i, (Ci, a_pw.L, NP))
+            segs = [dz_segs(dy, z, bn, Co, Lo, pos_mul=s_, pos_off=kk - pad, woff=kk) for kk in range(k)]
+            nparts = self._gemm(w, N=N, NP=NP, P=a_pw.L, M=Ci, out=dy_pw, out_L=a_pw.L, W=ct.weight.data,
+                                ldw_m=Co * k, ldw_c=k, segs=segs, zmask=a_pw.t, e0=a_pw.bn.scale, e1=a_pw.bn.shift,
+                                e2=a_pw.bn.mean, stats=Ci)
+            self._bn_bwd(w, a_pw.bn, nparts, grads)
+            dy, z, bn = dy_pw, a_pw.t, a_pw.bn
+            # pointwise conv over [x1 | skip]
+            Kin = pw.in_channels
+            if i > 0:
+                x1 = acts["dec%d" % (i - 1)]
+                skip = acts["enc%d" % (5 - i)]
+                left = (skip.L - x1.L) // 2
+                srcs = [x1.seg(pos_off=-left, woff=0), skip.seg(woff=x1.C)]
+            else:
+                x1 = acts["fgru"]
+                skip, left = None, 0
+                srcs = [x1.seg()]
+            Lp = a_pw.L
+            self._wgrad(w, N=N, NP=NP, P=Lp, M=pw.out_channels, dz=dy, dz1=z, dz_L=Lp, dz_bn=bn, W=pw.weight,
+                        ldw_m=Kin, ldw_c=1, segs=srcs, grads=grads, bias=pw.bias)
+            # data gradient, x1 part -> dy of x1's BN
+            p0, p1 = max(0, left), min(Lp, x1.L + left)
+            dy_x1 = w.get("dy:" + ("dec%d" % (i - 1) if i > 0 else "fgru"), (x1.C, x1.L, NP),
+                          zero=(p1 - p0 < x1.L))
+            nparts = self._gemm(w, N=N, NP=NP, P=p1 - p0, p_begin=p0, M=x1.C, out=dy_x1, out_L=x1.L,
+                                out_pos_off=-left, W=pw.weight.data, ldw_m=1, ldw_c=Kin,
+                                segs=[dz_segs(dy, z, bn, pw.out_channels, Lp)], zmask=x1.t, e0=x1.bn.scale,
+                                e1=x1.bn.shift, e2=x1.bn.mean, stats=x1.C)
+            self._bn_bwd(w, x1.bn, nparts, grads)
+            if skip is not None:   # raw (unmasked) gradient w.r.t. the skip activation
+                g_skip = w.get("dy:enc%d" % (5 - i), (skip.C, skip.L, NP))
+                self._gemm(w, N=N, NP=NP, P=Lp, M=skip.C, out=g_skip, out_L=skip.L, W=pw.weight.data, ldw_m=1,
+                           ldw_c=Kin, w_m_off=x1.C, segs=[dz_segs(dy, z, bn, pw.out_channels, Lp)])
+            dy, z, bn = dy_x1, x1.t, x1.bn
+
+        # -------- FGRU.conv (pw over hout)
+        conv = net.FGRU.conv[0]
+        hout = acts["hout"]
+        gru = net.FGRU.GRU
+        Hh, Lg = gru.hidden_size, hout.L
+        self._wgrad(w, N=N, NP=NP, P=Lg, M=conv.out_channels, dz=dy, dz1=z, dz_L=Lg, dz_bn=bn, W=conv.weight,
+                    ldw_m=conv.in_channels, ldw_c=1, segs=[hout.seg()], grads=grads, bias=conv.bias)
+        dhout = w.get("dhout", (2 * Hh, Lg, NP))
+        self._gemm(w, N=N, NP=NP, P=Lg, M=2 * Hh, out=dhout, out_L=Lg, W=conv.weight.data, ldw_m=1,
+                   ldw_c=conv.in_channels, segs=[dz_segs(dy, z, bn, conv.out_channels, Lg)])
+        # -------- GRU recurrence backward
+        dgi = w.get("dgi", (6 * Hh, Lg, NP))
+        dghn = w.get("dghn", (2 * Hh, Lg, NP))
+        gates = w.t["gates"]
+        check(lib.trunet_gru_bwd(ptr(dhout), ptr(hout.t), ptr(gates), ptr(gru.weight_hh_l0.data),
+                                 ptr(gru.weight_hh_l0_reverse.data), ptr(dgi), ptr(dghn), Hh, Lg, NP, N, st), "gru_bwd")
+        enc5 = acts["enc5"]
+        for d, sfx in enumerate(("", "_reverse")):
+            whh = getattr(gru, "weight_hh_l0" + sfx)
+            bhh = getattr(gru, "bias_hh_l0" + sfx)
+            wih_p = getattr(gru, "weight_ih_l0" + sfx)
+            bih_p = getattr(gru, "bias_ih_l0" + sfx)
+            hseg = make_seg(hout.t[d * Hh:(d + 1) * Hh], Hh, Lg, pos_off=(1 if d else -1))
+            gw = torch.empty_like(whh)
+            gb = torch.empty_like(bhh)
+            nparts = lib.trunet_conv_wgrad_nparts()
+            # rows 0..2H-1 (r, z) come from dgi, rows 2H..3H-1 (n) from dghn
+            self._wgrad(w, N=N, NP=NP, P=Lg, M=2 * Hh, dz=dgi, dz_L=Lg, dz_bn=None, a_m_off=d * 3 * Hh, W=whh,
+                        ldw_m=Hh, ldw_c=1, segs=[hseg], grads=grads, reduce=False, b_total=3 * Hh, b_off=0)
+            self._wgrad(w, N=N, NP=NP, P=Lg, M=Hh, dz=dghn, dz_L=Lg, dz_bn=None, a_m_off=d * Hh, w_m_off=2 * Hh,
+                        W=whh, ldw_m=Hh, ldw_c=1, segs=[hseg], grads=grads, reduce=False, b_total=3 * Hh,
+                        b_off=2 * Hh)
+            check(lib.trunet_reduce_partials(ptr(gw), ptr(w.t["w_partials"]), nparts, whh.numel(), 0, st), "reduce")
+            check(lib.trunet_reduce_partials(ptr(gb), ptr(w.t["b_partials"]), nparts, 3 * Hh, 0, st), "reduce")
+            grads[whh], grads[bhh] = gw, gb
+            # input projection weights: rows of dgi for this direction (3H = 128 + 64)
+            gwi = torch.empty_like(wih_p)
+            gbi = torch.empty_like(bih_p)
+            self._wgrad(w, N=N, NP=NP, P=Lg, M=2 * Hh, dz=dgi, dz_L=Lg, dz_bn=None, a_m_off=d * 3 * Hh, W=wih_p,
+                        ldw_m=gru.input_size, ldw_c=1, segs=[enc5.seg()], grads=grads, reduce=False,
+                        b_total=3 * Hh, b_off=0)
+            self._wgrad(w, N=N, NP=NP, P=Lg, M=Hh, dz=dgi, dz_L=Lg, dz_bn=None, a_m_off=d * 3 * Hh + 2 * Hh,
+                        w_m_off=2 * Hh, W=wih_p, ldw_m=gru.input_size, ldw_c=1, segs=[enc5.seg()], grads=grads,
+                        reduce=False, b_total=3 * Hh, b_off=2 * Hh)
+            check(lib.trunet_reduce_partials(ptr(gwi), ptr(w.t["w_partials"]), nparts, wih_p.numel(), 0, st), "reduce")
+            check(lib.trunet_reduce_partials(ptr(gbi), ptr(w.t["b_partials"]), nparts, 3 * Hh, 0, st), "reduce")
+            grads[wih_p], grads[bih_p] = gwi, gbi
+        # data gradient of the projection -> dy of enc5's BN
+        wih = w.t["wih"]
+        dy5 = w.get("dy:enc5", (enc5.C, enc5.L, NP))
+        nparts = self._gemm(w, N=N, NP=NP, P=Lg, M=enc5.C, out=dy5, out_L=enc5.L, W=wih, ldw_m=1,
+                            ldw_c=gru.input_size, segs=[make_seg(dgi, 6 * Hh, Lg)], zmask=enc5.t,
+                            e0=enc5.bn.scale, e1=enc5.bn.shift, e2=enc5.bn.mean, stats=enc5.C)
+        self._bn_bwd(w, enc5.bn, nparts, grads)
+        dy, z, bn = dy5, enc5.t, enc5.bn
+
+        # -------- encoder 5..1
+        for i in range(5, 0, -1):
+            seq = net.encoder[i].DepthwiseSeparableConv1d
+            pw, dwc = seq[0], seq[3]
+            a_pw = acts["enc%d.pw" % i]
+            a_dw = acts["enc%d" % i]
+            k, s_ = dwc.kernel_size[0], dwc.stride[0]
+            C = dwc.out_channels
+            dy_pw = w.get("dy:enc%d.pw" % i, (C, a_pw.L, NP))
+            nparts = lib.trunet_dwconv_bwd_nparts(a_pw.L)
+            part = w.flat("partials_dw", nparts * C * 2)
+            wpart = w.flat("dw_w_partials", nparts * C * k)
+            bpart = w.flat("dw_b_partials", nparts * C)
+            check(lib.trunet_dwconv_bwd(ptr(dy), ptr(z), ptr(bn.ca), ptr(bn.cb), ptr(bn.cc), ptr(a_pw.t),
+                                        ptr(a_pw.bn.scale), ptr(a_pw.bn.shift), ptr(a_pw.bn.mean),
+                                        ptr(dwc.weight.data), ptr(dy_pw), ptr(part), ptr(wpart), ptr(bpart), C, k, s_,
+                                        a_pw.L, a_dw.L, NP, N, st), "dwconv_bwd")
+            gw = torch.empty_like(dwc.weight)
+            gb = torch.empty_like(dwc.bias)
+            check(lib.trunet_reduce_partials(ptr(gw), ptr(wpart), nparts, C * k, 0, st), "reduce")
+            check(lib.trunet_reduce_partials(ptr(gb), ptr(bpart), nparts, C, 0, st), "reduce")
+            grads[dwc.weight], grads[dwc.bias] = gw, gb
+            self._bn_bwd(w, a_pw.bn, nparts, grads, part_name="partials_dw")
+            dy, z, bn = dy_pw, a_pw.t, a_pw.bn
+            prev = acts["enc%d" % (i - 1)]
+            Lp = a_pw.L
+            self._wgrad(w, N=N, NP=NP, P=Lp, M=pw.out_channels, dz=dy, dz1=z, dz_L=Lp, dz_bn=bn, W=pw.weight,
+                        ldw_m=pw.in_channels, ldw_c=1, segs=[prev.seg()], grads=grads, bias=pw.bias)
+            # data gradient -> dy of prev (accumulating the decoder's skip gradient already stored there)
+            dy_prev = w.get("dy:enc%d" % (i - 1), (prev.C, prev.L, NP))
+            has_skip = (i - 1) <= 4
+            if prev.bn is not None:
+                nparts = self._gemm(w, N=N, NP=NP, P=Lp, M=prev.C, out=dy_prev, out_L=prev.L, W=pw.weight.data,
+                                    ldw_m=1, ldw_c=pw.in_channels, segs=[dz_segs(dy, z, bn, pw.out_channels, Lp)],
+                                    epi=(EPI_ACCUM if has_skip else 0), zmask=prev.t, e0=prev.bn.scale,
+                                    e1=prev.bn.shift, e2=prev.bn.mean, stats=prev.C)
+                self._bn_bwd(w, prev.bn, nparts, grads)
+                dy, z, bn = dy_prev, prev.t, prev.bn
+            else:   # enc0: ReLU only (mask = a0 > 0), no BN
+                one = w.get("ones64", (prev.C,))
+                zero = w.get("zeros64", (prev.C,))
+                one.fill_(1.0)
+                zero.zero_()
+                self._gemm(w, N=N, NP=NP, P=Lp, M=prev.C, out=dy_prev, out_L=prev.L, W=pw.weight.data, ldw_m=1,
+                           ldw_c=pw.in_channels, segs=[dz_segs(dy, z, bn, pw.out_channels, Lp)], epi=EPI_ACCUM,
+                           zmask=prev.t, e0=one, e1=zero, e2=zero)
+                dy, z, bn = dy_prev, None, None
+
+        # -------- first conv: weight/bias gradient (one segment per tap of the input)
+        c0 = net.encoder[0].StandardConv1d[0]
+        xa = acts["x"]
+        k, s_, pad = c0.kernel_size[0], c0.stride[0], c0.padding[0]
+        segs = [make_seg(xa.t, xa.C, xa.L, pos_mul=s_, pos_off=kk - pad, woff=kk) for kk in range(k)]
+        self._wgrad(w, N=N, NP=NP, P=128, M=c0.out_channels, dz=dy, dz_L=128, dz_bn=None, W=c0.weight,
+                    ldw_m=xa.C * k, ldw_c=k, segs=segs, grads=grads, bias=c0.bias)
+        return grads

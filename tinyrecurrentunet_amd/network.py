@@ -1,0 +1,154 @@
+"""MI355X-native ``network`` module: same classes, constructor signatures and ``state_dict`` keys
+as ``/root/reference/network.py`` (blocks :9-120, ``TRUNet`` :122-171 in the repaired composition
+R1-R4 of SURVEY.md section 0.2), with every forward/backward running on the hand-written HIP
+kernels of libtrunet_hip.so.  The ``torch.nn`` layers below are parameter containers only (they
+give the reference's parameter names, shapes and default initialisation); their own ``forward``
+is never called.  There is no CPU path: calling a module with a CPU tensor raises.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .engine import TRUNetEngine
+
+
+def _need_gpu(x):
+    if not x.is_cuda:
+        raise _lib.TrunetHipError("tinyrecurrentunet_amd runs on MI355X only: got a %s tensor "
+                                  "(the CPU restatement lives in oracle/, for tests)" % x.device)
+    _lib.lib()
+
+
+def _pw_bn_relu(cin, cout):
+    return [nn.Conv1d(cin, cout, kernel_size=1), nn.BatchNorm1d(cout), nn.ReLU(inplace=True)]
+
+
+class StandardConv1d(nn.Module):
+    """network.py:9-21."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride):
+        super().__init__()
+        self.StandardConv1d = nn.Sequential(
+            nn.Conv1d(in_channels, out_channels, kernel_size, stride=stride, padding=stride // 2),
+            nn.ReLU(inplace=True))
+
+
+class DepthwiseSeparableConv1d(nn.Module):
+    """network.py:24-43."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride):
+        super().__init__()
+        self.DepthwiseSeparableConv1d = nn.Sequential(
+            *_pw_bn_relu(in_channels, out_channels),
+            nn.Conv1d(out_channels, out_channels, kernel_size, stride=stride, padding=kernel_size // 2,
+                      groups=out_channels),
+            nn.BatchNorm1d(out_channels), nn.ReLU(inplace=True))
+
+
+class GRUBlock(nn.Module):
+    """network.py:45-58."""
+
+    def __init__(self, in_channels, hidden_size, out_channels, bidirectional):
+        super().__init__()
+        self.GRU = nn.GRU(in_channels, hidden_size, batch_first=True, bidirectional=bidirectional)
+        width = hidden_size * (2 if bidirectional else 1)
+        self.conv = nn.Sequential(*_pw_bn_relu(width, out_channels))
+
+
+def _trcnn_body(in_channels, out_channels, kernel_size, stride, tail=True):
+    layers = _pw_bn_relu(in_channels, out_channels)
+    layers.append(nn.ConvTranspose1d(out_channels, out_channels, kernel_size, stride=stride, padding=stride // 2))
+    if tail:
+        layers += [nn.BatchNorm1d(out_channels), nn.ReLU(inplace=True)]
+    return nn.Sequential(*layers)
+
+
+class FirstTrCNN(nn.Module):
+    """network.py:60-76."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride):
+        super().__init__()
+        self.FirstTrCNN = _trcnn_body(in_channels, out_channels, kernel_size, stride)
+
+
+class TrCNN(nn.Module):
+    """network.py:79-100."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride):
+        super().__init__()
+        self.TrCNN = _trcnn_body(in_channels, out_channels, kernel_size, stride)
+
+
+class LastTrCNN(nn.Module):
+    """network.py:102-120."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride):
+        super().__init__()
+        self.LastTrCNN = _trcnn_body(in_channels, out_channels, kernel_size, stride, tail=False)
+
+
+class _TRUNetFn(torch.autograd.Function):
+    """One autograd node for the whole body: forward and backward are the HIP schedules of
+    ``engine.TRUNetEngine``; gradients are produced for the parameters only (the input features
+    carry no gradient in the reference either, util.py:214-218)."""
+
+    @staticmethod
+    def forward(ctx, x, engine, training, *params):
+        out, ectx = engine.forward(x, training)
+        ctx.engine, ctx.ectx, ctx.params = engine, ectx, params
+        ctx.training = training
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        if not ctx.training:
+            raise _lib.TrunetHipError("backward through TRUNet in eval() mode is not supported "
+                                      "(BatchNorm running statistics); call net.train()")
+        grads = ctx.engine.backward(ctx.ectx, gout)
+        return (None, None, None) + tuple(grads.get(p) for p in ctx.params)
+
+
+class TRUNet(nn.Module):
+    """Tiny Recurrent U-Net body: (N, C_in, 257) -> (N, 8, 257), N = frames.
+
+    Constructor arguments as in network.py:123-130; like the reference only the layer sizes of
+    network.py:134-150 exist, and ``input_size`` sets the first conv's channels (R2).  ``TGRU`` is
+    registered for checkpoint parity and not executed (R4)."""
+
+    def __init__(self, input_size=3, channels_input=64, channels_output=3, channels_hidden=128,
+                 kernel_sizes=(5, 3), strides=(2, 1), tr_channels_input=192):
+        super().__init__()
+        self.encoder = nn.ModuleList([
+            StandardConv1d(input_size, 64, 5, 2),
+            DepthwiseSeparableConv1d(64, 128, 3, 1),
+            DepthwiseSeparableConv1d(128, 128, 5, 2),
+            DepthwiseSeparableConv1d(128, 128, 3, 1),
+            DepthwiseSeparableConv1d(128, 128, 5, 2),
+            DepthwiseSeparableConv1d(128, 128, 3, 2)])
+        self.decoder = nn.ModuleList([
+            FirstTrCNN(64, 64, 3, 2),
+            TrCNN(192, 64, 5, 2),
+            TrCNN(192, 64, 3, 1),
+            TrCNN(192, 64, 5, 2),
+            TrCNN(192, 64, 3, 1),
+            LastTrCNN(128, 8, 5, 2)])
+        self.FGRU = GRUBlock(128, 64, 64, bidirectional=True)
+        self.TGRU = GRUBlock(64, 128, 64, bidirectional=False)
+        self._engine = None
+
+    def _active_params(self):
+        return [p for n, p in self.named_parameters() if not n.startswith("TGRU.")]
+
+    def forward(self, x):
+        _need_gpu(x)
+        if self._engine is None:
+            self._engine = TRUNetEngine(self)
+        params = self._active_params()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            return _TRUNetFn.apply(x, self._engine, self.training, *params)
+        out, _ = self._engine.forward(x, self.training)
+        return out
+
+
+# train.py:22 imports this name (it does not exist in the reference either): alias only.
+TRUNet2D = TRUNet
