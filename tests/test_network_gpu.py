@@ -7,8 +7,30 @@ pytestmark = pytest.mark.gpu
 
 
 def _rel(a, b):
-    a, b = a.double().cpu(), b.double().cpu()
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def _errs(g, ref):
+    g, ref = g.detach().double().cpu(), ref.detach().double().cpu()
+    d = g - ref
+    return float(d.abs().max()), float(d.norm()), float(ref.abs().max()), float(ref.norm())
+
+
+def _grad_close(g, ref, name, errs=None):
+    """Gradient parity metric.  A weight-gradient element is a sum of ~N*L products gated by ReLU
+    masks, and BatchNorm makes several of these sums strongly cancelling, so fp32 rounding is
+    amplified in EVERY fp32 implementation.  Measured vs the fp64 oracle (N=300,
+    tests/gpu_debug_grad_precision.py, relative L2 per tensor, median / max over the 100 tensors):
+    HIP 2.9e-3 / 1.2e-2, torch CPU fp32 4.7e-3 / 6.4e-3, torch GPU fp32 1.2e-2 / 2.5e-2.
+    Bounds: 3e-2 relative L2 and 3e-2 of max|g| per element for every tensor; callers also bound
+    the median.  Conv biases in front of a BatchNorm have an analytically zero gradient (rounding
+    noise in the reference), hence the absolute floors."""
+    emax, el2, rmax, rl2 = _errs(g, ref)
+    assert emax < 3e-2 * rmax + 2e-3, (name, emax, rmax)
+    assert el2 < 3e-2 * rl2 + 2e-3, (name, el2, rl2)
+    if errs is not None and rmax > 1e-3:
+        errs.append(el2 / rl2)
 
 
 def _nets(cin, seed=0):
@@ -51,9 +73,7 @@ def test_backward_matches_golden(golden, cin):
             continue
         ref = torch.tensor(g["g:" + pn])
         n += p.numel()
-        # conv biases in front of a BatchNorm have an analytically zero gradient: absolute check only
-        tol = 2e-3 * float(ref.abs().max()) + 2e-4
-        assert float((p.grad.cpu() - ref).abs().max()) < tol, pn
+        _grad_close(p.grad, ref, pn)
     assert n == int(g["n_grad_params"])
     for bn_, b in net.named_buffers():
         if b.is_floating_point() and not bn_.startswith("TGRU"):
@@ -75,6 +95,7 @@ def test_forward_backward_vs_oracle_f64(N):
         return    # BatchNorm training statistics need more than one value per channel
     refd.train(); net.train()
     yd = refd(x.double()); (yd * cot.double()).sum().backward()
+    errs = []
     y = net(x.cuda()); (y * cot.cuda()).sum().backward()
     assert _rel(y, yd) < 1e-4
     pd = dict(refd.named_parameters())
@@ -82,8 +103,8 @@ def test_forward_backward_vs_oracle_f64(N):
         if pn.startswith("TGRU"):
             continue
         ref_g = pd[pn].grad
-        tol = 1e-3 * float(ref_g.abs().max()) + 1e-4
-        assert float((p.grad.double().cpu() - ref_g).abs().max()) < tol, pn
+        _grad_close(p.grad, ref_g, pn, errs)
+    assert float(np.median(errs)) < 8e-3, float(np.median(errs))
 
 
 def test_state_dict_keys_match_reference_layout():
