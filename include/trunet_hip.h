@@ -177,6 +177,40 @@ int trunet_adamw(float* p, const float* g, float* m, float* v, int64_t n, float 
 /* sum of squares -> out[0] (clip_grad_norm_ total norm^2, train.py:138) */
 int trunet_sumsq(const float* g, int64_t n, float* out, void* stream);
 
+
+/* ---- FFT-based front / back end (all sizes fp32; tw = exp(-2*pi*i*t/n), t < n/2, interleaved re,im) ---- */
+
+/* ProcessAudio.forward (dataset.py:246-272): rectangular-window, centre/reflect STFT (n_fft 512, hop 128)
+ * of B utterances -> feat (B*T, C, 257), T = 1 + L/128; C = 3: (norm-dB-mag, sin, cos) (dataset.py:268-270),
+ * C = 4: channel 1 is left for trunet_pcen.  mag (B, T, 257) is written when non-NULL. */
+int trunet_stft_features(const float* audio, float* feat, float* mag, const float* tw512, int B, int L, int T,
+                         int C, void* stream);
+/* pcenfunc (dataset.py:56-76) on mag (B, T, 257); out points at channel 1 of feat, out_stride = C*257 */
+int trunet_pcen(const float* mag, float* out, int B, int T, int out_stride, float eps, float s, float alpha,
+                float delta, float r, void* stream);
+/* R7 glue (util.py:217-235 intent; phm.py:31-45; dataset.py:182-203,293-296): net output (B*T, 8, 257) ->
+ * phase-aware mask -> rect-window iSTFT -> audio (B, L), L = 128 (T-1).  frames: scratch (B, T, 512).
+ * With clean != NULL also writes per-block sums of |audio - clean| (util.py:239) to l1_partials. */
+int trunet_mask_istft_fwd(const float* net_out, float* frames, float* audio, const float* clean,
+                          float* l1_partials, const float* tw512, int B, int T, int L, float beta, void* stream);
+int trunet_mask_istft_l1_nparts(int B, int L);
+int trunet_mask_istft_bwd(const float* g_audio, const float* net_out, float* g_net, const float* tw512, int B,
+                          int T, int L, float beta, void* stream);
+/* g[i] = scale[0] * sign(den[i] - clean[i])  (backward of nn.L1Loss, util.py:239) */
+int trunet_l1_grad(const float* den, const float* clean, const float* scale, float* g, int64_t n, void* stream);
+/* out[c] = sum_g partials[g*ncols + c] in fp64 */
+int trunet_reduce_cols(const float* partials, int nparts, int ncols, float* out, void* stream);
+/* One resolution of MultiResolutionSTFTLoss (stft_loss.py:9-113): win = Hann(win_length) zero-padded to n,
+ * frames = 1 + L/hop.  fwd: partials[(b*frames + f)][3] = sum (|Y|-|X|)^2, sum |Y|^2, sum |log|Y| - log|X||
+ * with |.| = sqrt(clamp(re^2+im^2, 1e-7)).  bwd: atomically adds d loss / d x into gx (B, L) given
+ * coef[0] = g_sc*lambda_sc/(nres*sqrt(S1)*sqrt(S2)), coef[1] = g_mag*lambda_mag/(nres*count). */
+int trunet_stft_loss_fwd(const float* x, const float* y, const float* win, const float* tw, float* partials,
+                         int B, int L, int n, int hop, void* stream);
+int trunet_stft_loss_bwd(const float* x, const float* y, const float* win, const float* tw, const float* coef,
+                         float* gx, int B, int L, int n, int hop, void* stream);
+/* PhaseAwareMask.forward (phm.py:31-45 + R5) on interleaved complex64: out = sigmoid(beta(angle m - angle e)) |m| */
+int trunet_phm_fwd(const float* mix_ri, const float* est_ri, float* out, int64_t n, float beta, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

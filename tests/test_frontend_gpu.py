@@ -1,0 +1,152 @@
+"""GPU parity of the FFT-based stages (features, PCEN, mask+iSTFT, losses, loss_fn) vs the oracle / goldens."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+CFG = dict(fft_sizes=[512, 1024, 2048], hop_sizes=[50, 120, 240], win_lengths=[240, 600, 1200],
+           sc_lambda=0.5, mag_lambda=0.5, band="full")
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def test_features_match_golden(golden):
+    from tinyrecurrentunet_amd import dataset as ds
+    g = golden("features")
+    audio = torch.tensor(g["audio"]).cuda()
+    pa = ds.ProcessAudio()
+    feat = pa(audio)
+    ref = torch.tensor(g["feat"])
+    assert feat.shape == ref.shape
+    # channel 0 (dB) and the unit-modulus phase channels: 1e-4 of range; a bin with |X| ~ 0 has an
+    # ill-defined phase, none occurs for this input
+    assert float((feat.cpu() - ref).abs().max()) < 2e-4
+    back = pa.backward(torch.tensor(g["feat"]).cuda())
+    assert _rel(back, torch.tensor(g["back"])) < 1e-4
+    back2 = pa.backward(torch.tensor(g["feat2"]).cuda())
+    assert _rel(back2, torch.tensor(g["back2"])) < 1e-4
+    f4 = ds.stft_features(audio[0], pcen=True)
+    assert _rel(f4[:, 1], torch.tensor(g["pcen_train"][0])) < 1e-4
+    assert float((f4[:, [0, 2, 3]].cpu() - ref).abs().max()) < 2e-4
+    mag = torch.stft(torch.tensor(g["audio"])[0], 512, 128, return_complex=True).abs().transpose(1, 2)
+    assert _rel(ds.pcenfunc(mag.cuda()), torch.tensor(g["pcen_eval"])) < 1e-4
+
+
+@pytest.mark.parametrize("B,L", [(1, 2048), (3, 16000)])
+def test_features_vs_oracle(B, L):
+    from oracle import features_ref as fr, weights as W
+    from tinyrecurrentunet_amd import dataset as ds
+    _, noisy = W.synth_pairs(B, L, seed=L)
+    ref = fr.features_batch(noisy, pcen=True)
+    out = ds.stft_features(noisy[:, 0].cuda(), pcen=True).cpu()
+    assert out.shape == ref.shape
+    # dB magnitude and phase of a bin whose magnitude is ~1e-5 of the largest are ill-conditioned in ANY fp32
+    # FFT (error ~1e-7 * |x| over 1e-5): compare (a) the complex spectrum the features encode, relative to its
+    # largest bin, (b) every channel directly on the bins above 1e-3 of the largest magnitude.
+    spec_o = fr.mod_phase(out[:, 0], out[:, 2], out[:, 3])
+    spec_r = fr.mod_phase(ref[:, 0], ref[:, 2], ref[:, 3])
+    assert float((spec_o - spec_r).abs().max() / spec_r.abs().max()) < 1e-4
+    strong = spec_r.abs() > 1e-3 * spec_r.abs().max()
+    for c in range(4):
+        assert float((out[:, c] - ref[:, c])[strong].abs().max()) < 3e-4, c
+    assert _rel(out[:, 1], ref[:, 1]) < 1e-4
+
+
+def test_mrstft_matches_golden(golden):
+    from tinyrecurrentunet_amd import stft_loss as sl
+    g = golden("mrstft")
+    m = sl.MultiResolutionSTFTLoss(**CFG).cuda()
+    x = torch.tensor(g["x"]).cuda().requires_grad_(True)
+    sc, mag = m(x, torch.tensor(g["y"]).cuda())
+    assert abs(float(sc) - float(g["sc"])) < 1e-4 * float(g["sc"])
+    assert abs(float(mag) - float(g["mag"])) < 1e-4 * float(g["mag"])
+    (sc + mag).backward()
+    assert _rel(x.grad, torch.tensor(g["gx"])) < 1e-3
+    torch.manual_seed(0)
+    xs, ys = torch.randn(2, 16000), torch.randn(2, 16000)
+    ksc, kmag = m(xs.cuda(), ys.cuda())
+    assert abs(float(ksc) - 0.33027813) < 3e-5 and abs(float(kmag) - 0.35075721) < 3e-5
+
+
+def test_phm_vs_oracle():
+    from oracle import features_ref as fr
+    from tinyrecurrentunet_amd import phm
+    torch.manual_seed(1)
+    m = torch.randn(257, 33, dtype=torch.cfloat)
+    e = torch.randn(257, 33, dtype=torch.cfloat)
+    out = phm.PhaseAwareMask(0.5)(m.cuda(), e.cuda())
+    assert _rel(out, fr.phase_aware_mask(m, e, 0.5)) < 1e-5
+
+
+@pytest.mark.parametrize("B,L", [(2, 4096), (3, 16000)])
+def test_denoise_and_grad_vs_oracle(B, L):
+    """mask + iSTFT + L1 stage (R7), forward and backward, vs the oracle in fp64."""
+    from oracle import features_ref as fr
+    from tinyrecurrentunet_amd import util
+    T = 1 + L // 128
+    rng = np.random.default_rng(B * L)
+    out = torch.tensor(rng.standard_normal((B * T, 8, 257)) * 0.7, dtype=torch.float32)
+    clean = torch.tensor(rng.standard_normal((B, L)) * 0.1, dtype=torch.float32)
+    o64 = out.double().requires_grad_(True)
+    den64 = fr.denoise_from_output(o64, T, 0.5, length=L)
+    cot = torch.tensor(rng.standard_normal((B, L)), dtype=torch.float64)
+    l164 = (den64 - clean.double()).abs().mean()
+    ((den64 * cot).sum() + 3.0 * l164).backward()
+    og = out.cuda().requires_grad_(True)
+    den, l1 = util.denoise(og, clean.cuda(), T)
+    assert _rel(den, den64) < 1e-4
+    assert abs(float(l1) - float(l164)) < 1e-5 * float(l164)
+    ((den * cot.float().cuda()).sum() + 3.0 * l1).backward()
+    assert _rel(og.grad, o64.grad) < 1e-3
+
+
+def test_loss_fn_end_to_end_vs_oracle():
+    """Whole train-step loss (R7) and its parameter gradients vs the oracle composition."""
+    from oracle import loss_ref, network_ref as nr, weights as W
+    from tinyrecurrentunet_amd import network as hn, stft_loss as sl, util
+    B, L = 2, 8192
+    clean, noisy = W.synth_pairs(B, L, seed=7)
+    ref = W.fill_state_dict(nr.TRUNet(input_size=4), seed=0).double().train()
+    loss64, info64, den64 = loss_ref.loss_fn(ref, clean.double(), noisy.double(), stft_config=CFG, pcen=True)
+    loss64.backward()
+    net = hn.TRUNet(input_size=4)
+    net.load_state_dict(W.fill_state_dict(nr.TRUNet(input_size=4), seed=0).state_dict())
+    net.cuda().train()
+    mr = sl.MultiResolutionSTFTLoss(**CFG).cuda()
+    loss, info = util.loss_fn(net, (clean.cuda(), noisy.cuda()), ell_p=1, ell_p_lambda=1, stft_lambda=1, mrstftloss=mr)
+    loss.backward()
+    assert abs(float(loss) - float(loss64)) < 2e-4 * abs(float(loss64))
+    for k in ("l1", "stft_sc", "stft_mag"):
+        assert abs(float(info[k]) - float(info64[k])) < 5e-4 * abs(float(info64[k])) + 1e-7, k
+    pd = dict(ref.named_parameters())
+    errs = []
+    for pn, p in net.named_parameters():
+        if pn.startswith("TGRU"):
+            continue
+        r = pd[pn].grad
+        if float(r.abs().max()) < 1e-9:
+            continue
+        errs.append(float((p.grad.double().cpu() - r).norm() / r.norm()))
+    assert float(np.median(errs)) < 2e-2 and max(errs) < 2e-1, (np.median(errs), max(errs))
+
+
+def test_fused_adamw_matches_torch():
+    from tinyrecurrentunet_amd import optim
+    torch.manual_seed(0)
+    ps = [torch.randn(7, 5, device="cuda", requires_grad=True), torch.randn(11, device="cuda", requires_grad=True)]
+    qs = [p.detach().clone().requires_grad_(True) for p in ps]
+    a = optim.FusedAdamW(ps, lr=4e-4)
+    b = torch.optim.AdamW(qs, lr=4e-4)
+    for it in range(5):
+        for p, q in zip(ps, qs):
+            g = torch.randn_like(p)
+            p.grad, q.grad = g.clone(), g.clone()
+        nsq = a.step()
+        b.step()
+        tot = sum(float((q.grad ** 2).sum()) for q in qs)
+        assert abs(float(nsq) - tot) < 1e-4 * tot
+    for p, q in zip(ps, qs):
+        assert _rel(p, q) < 1e-5

@@ -85,6 +85,16 @@ def _declare(L):
         "trunet_gru_bwd": [p, p, p, p, p, p, p, i, i, i, i, p],
         "trunet_adamw": [p, p, p, p, i64, f, f, f, f, f, i, p],
         "trunet_sumsq": [p, i64, p, p],
+        "trunet_stft_features": [p, p, p, p, i, i, i, i, p],
+        "trunet_pcen": [p, p, i, i, i, f, f, f, f, f, p],
+        "trunet_mask_istft_fwd": [p, p, p, p, p, p, i, i, i, f, p],
+        "trunet_mask_istft_l1_nparts": [i, i],
+        "trunet_mask_istft_bwd": [p, p, p, p, i, i, i, f, p],
+        "trunet_l1_grad": [p, p, p, p, i64, p],
+        "trunet_reduce_cols": [p, i, i, p, p],
+        "trunet_stft_loss_fwd": [p, p, p, p, p, i, i, i, i, p],
+        "trunet_stft_loss_bwd": [p, p, p, p, p, p, i, i, i, i, p],
+        "trunet_phm_fwd": [p, p, p, i64, f, p],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -124,3 +134,17 @@ def make_seg(src0, nchan, L, pos_mul=1, pos_off=0, pos_div=1, woff=0, mode=PRO_N
     s.pos_mul, s.pos_off, s.pos_div = pos_mul, pos_off, pos_div
     s.woff, s.mode = woff, mode
     return s
+
+
+_TW = {}
+
+
+def twiddles(n, device):
+    """exp(-2*pi*i*t/n), t < n/2, as an (n/2, 2) fp32 device tensor (computed once in fp64)."""
+    key = (n, str(device))
+    if key not in _TW:
+        import numpy as np
+        t = np.arange(n // 2, dtype=np.float64)
+        w = np.stack([np.cos(2 * np.pi * t / n), -np.sin(2 * np.pi * t / n)], 1)
+        _TW[key] = torch.tensor(w, dtype=torch.float32, device=device).contiguous()
+    return _TW[key]

@@ -1,0 +1,451 @@
+// FFT-based stages of the hot path, one LDS Stockham radix-2 FFT per workgroup (256 threads):
+//   * STFT features  (dataset.py:246-272): rect-window rFFT-512 -> (norm-dB-mag, [PCEN], sin, cos)
+//   * PCEN           (dataset.py:56-76)
+//   * mask + iSTFT   (phm.py:31-45 + R5, dataset.py:182-203,275-298): net output -> audio, and its backward
+//   * L1 loss        (util.py:239-240)
+//   * multi-resolution STFT loss (stft_loss.py:9-166), forward sums and backward
+// Two real sequences share one complex FFT (z = a + j b;  A[k] = (Z[k] + conj Z[N-k])/2,
+// B[k] = (Z[k] - conj Z[N-k])/(2j)): two STFT frames per transform in the feature / iSTFT kernels,
+// the (predicted, target) pair of one frame in the loss kernels.  All of these stages are HBM-bound.
+#include "common.hpp"
+
+namespace {
+
+typedef float2 cpx;
+
+__device__ __forceinline__ cpx cmul(cpx a, cpx b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ cpx cconj(cpx a) { return make_float2(a.x, -a.y); }
+
+// In-LDS Stockham autosort FFT of size n = 2^logn by all 256 threads of the block.
+// tw[t] = exp(-2*pi*i*t/n), t < n/2.  inverse => conjugated twiddles (unnormalised).
+// Returns the buffer (a or b) that holds the natural-order result.  Ends with a barrier.
+__device__ cpx* fft_lds(cpx* a, cpx* b, int n, int logn, const cpx* __restrict__ tw, bool inverse) {
+    const int half = n >> 1;
+    cpx* x = a;
+    cpx* y = b;
+    int ns = 1;
+    for (int s = 0; s < logn; ++s) {
+        __syncthreads();
+        const int tstep = half >> s;  // n / (2*ns)
+        for (int j = threadIdx.x; j < half; j += blockDim.x) {
+            const int k = j & (ns - 1);
+            cpx w = tw[k * tstep];
+            if (inverse) w.y = -w.y;
+            const cpx u = x[j];
+            const cpx v = cmul(w, x[j + half]);
+            const int j0 = ((j - k) << 1) + k;
+            y[j0] = make_float2(u.x + v.x, u.y + v.y);
+            y[j0 + ns] = make_float2(u.x - v.x, u.y - v.y);
+        }
+        cpx* t = x; x = y; y = t;
+        ns <<= 1;
+    }
+    __syncthreads();
+    return x;
+}
+
+__device__ __forceinline__ int reflect_idx(int j, int L) {
+    if (j < 0) j = -j;
+    if (j >= L) j = 2 * (L - 1) - j;
+    return j;
+}
+
+constexpr int NF = 512;      // feature STFT size (dataset.py:133)
+constexpr int HOPF = 128;    // dataset.py:134
+constexpr int BINS = 257;
+
+__device__ __forceinline__ void split_pair(const cpx* Z, int k, int n, cpx& A, cpx& B) {
+    const cpx zk = Z[k];
+    const cpx zn = cconj(Z[(n - k) & (n - 1)]);
+    A = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y + zn.y));
+    // (zk - zn) / (2j) = (-j/2) (zk - zn)
+    B = make_float2(0.5f * (zk.y - zn.y), -0.5f * (zk.x - zn.x));
+}
+
+// ---------------------------------------------------------------- STFT features
+// grid (ceil(T/2), B); feat: (B*T, C, 257); mag (optional): (B, T, 257)
+__global__ __launch_bounds__(256) void stft_features_kernel(const float* __restrict__ audio, float* __restrict__ feat,
+                                                            float* __restrict__ mag_out, const cpx* __restrict__ tw,
+                                                            int L, int T, int C) {
+    __shared__ cpx sa[NF], sb[NF];
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * 2;
+    const float* x = audio + (size_t)b * L;
+    for (int i = threadIdx.x; i < NF; i += 256) {
+        const float va = x[reflect_idx(t0 * HOPF + i - NF / 2, L)];
+        const float vb = (t0 + 1 < T) ? x[reflect_idx((t0 + 1) * HOPF + i - NF / 2, L)] : 0.f;
+        sa[i] = make_float2(va, vb);
+    }
+    const cpx* Z = fft_lds(sa, sb, NF, 9, tw, false);
+    for (int k = threadIdx.x; k < BINS; k += 256) {
+        cpx X[2];
+        split_pair(Z, k, NF, X[0], X[1]);
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int t = t0 + f;
+            if (t >= T) continue;
+            const float re = X[f].x, im = X[f].y;
+            const float mag = sqrtf(re * re + im * im);
+            // dataset.py:207-211 amp_to_db, :229-235 norm
+            const float db = 20.f * log10f(fmaxf(mag, 1e-7f)) - 25.f;
+            float nm = ((db + 100.f) / 100.f) * 2.f - 1.f;
+            nm = fminf(fmaxf(nm, -1.f), 1.f);
+            float sn = 0.f, cs = 1.f;       // angle(0) = 0
+            if (mag > 0.f) { sn = im / mag; cs = re / mag; }
+            float* o = feat + ((size_t)(b * T + t) * C) * BINS + k;
+            o[0] = nm;
+            o[(size_t)(C - 2) * BINS] = sn;
+            o[(size_t)(C - 1) * BINS] = cs;
+            if (mag_out) mag_out[((size_t)b * T + t) * BINS + k] = mag;
+        }
+    }
+}
+
+// PCEN (dataset.py:56-76): M[0] = s x[0]; M[t] = (1-s) M[t-1] + s x[t]; (x/(M+eps)^alpha + delta)^r - delta^r
+__global__ void pcen_kernel(const float* __restrict__ mag, float* __restrict__ out, int T, int out_stride, float eps,
+                            float s, float alpha, float delta, float r) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (k >= BINS) return;
+    const float* x = mag + (size_t)b * T * BINS + k;
+    float* o = out + (size_t)b * T * out_stride + k;
+    const float dr = powf(delta, r);
+    float M = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const float v = x[(size_t)t * BINS];
+        M = (t == 0) ? s * v : (1.f - s) * M + s * v;
+        o[(size_t)t * out_stride] = powf(v / powf(M + eps, alpha) + delta, r) - dr;
+    }
+}
+
+// ---------------------------------------------------------------- mask + iSTFT
+// Per bin of the net output o (8 channels, R7): A = 10^(2.5 (clamp(o0)+1) - 3.75);
+// phi_m = atan2(o2, o3); phi_n = atan2(o6, o7); M = sigmoid(beta (phi_m - phi_n)) A; X = M e^{j phi_m}.
+struct MaskVals { float A, S, cm, sm, r2m, r2n, c0; };
+
+__device__ __forceinline__ MaskVals mask_vals(const float* o, size_t cs, float beta) {
+    MaskVals v;
+    const float c0 = o[0], c2 = o[2 * cs], c3 = o[3 * cs], c6 = o[6 * cs], c7 = o[7 * cs];
+    v.c0 = c0;
+    const float cc = fminf(fmaxf(c0, -1.f), 1.f);
+    v.A = exp10f(2.5f * (cc + 1.f) - 3.75f);
+    v.r2m = c2 * c2 + c3 * c3;
+    v.r2n = c6 * c6 + c7 * c7;
+    const float pm = atan2f(c2, c3), pn = atan2f(c6, c7);
+    v.S = 1.f / (1.f + expf(-beta * (pm - pn)));
+    if (v.r2m > 0.f) { const float ir = rsqrtf(v.r2m); v.cm = c3 * ir; v.sm = c2 * ir; }
+    else { v.cm = 1.f; v.sm = 0.f; }
+    return v;
+}
+
+// grid (ceil(T/2), B); out_net: (B*T, 8, 257); frames: (B, T, 512) time-domain frames (irfft, 1/512)
+__global__ __launch_bounds__(256) void mask_istft_frames_kernel(const float* __restrict__ net_out,
+                                                                float* __restrict__ frames, const cpx* __restrict__ tw,
+                                                                int T, float beta) {
+    __shared__ cpx sa[NF], sb[NF];
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * 2;
+    for (int k = threadIdx.x; k < BINS; k += 256) {
+        cpx X[2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            X[f] = make_float2(0.f, 0.f);
+            const int t = t0 + f;
+            if (t < T) {
+                const MaskVals v = mask_vals(net_out + (size_t)(b * T + t) * 8 * BINS + k, BINS, beta);
+                const float M = v.S * v.A;
+                X[f] = make_float2(M * v.cm, M * v.sm);
+            }
+            if (k == 0 || k == NF / 2) X[f].y = 0.f;     // c2r ignores the imaginary part of DC / Nyquist
+        }
+        // Z = Xa_full + j Xb_full (Hermitian extensions)
+        sa[k] = make_float2(X[0].x - X[1].y, X[0].y + X[1].x);
+        if (k > 0 && k < NF / 2) sa[NF - k] = make_float2(X[0].x + X[1].y, -X[0].y + X[1].x);
+    }
+    const cpx* z = fft_lds(sa, sb, NF, 9, tw, true);
+    for (int i = threadIdx.x; i < NF; i += 256) {
+        const cpx v = z[i];
+        frames[((size_t)b * T + t0) * NF + i] = v.x * (1.f / NF);
+        if (t0 + 1 < T) frames[((size_t)b * T + t0 + 1) * NF + i] = v.y * (1.f / NF);
+    }
+}
+
+__device__ __forceinline__ float ola_env(int p, int T) {
+    // number of rectangular frames covering padded position p (window envelope of torch.istft)
+    int hi = p / HOPF;
+    if (hi > T - 1) hi = T - 1;
+    int lo = (p - NF + HOPF) / HOPF;      // ceil((p - 511)/128) for p >= 0
+    if (p - NF + 1 <= 0) lo = 0;
+    return (float)(hi - lo + 1);
+}
+
+// audio[b][j] = sum_t frames[b][t][j + 256 - 128 t] / env ; optional L1 partial sums vs clean
+__global__ __launch_bounds__(256) void ola_kernel(const float* __restrict__ frames, float* __restrict__ audio,
+                                                  const float* __restrict__ clean, float* __restrict__ l1_partials,
+                                                  int T, int L) {
+    __shared__ double red[256];
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    float ad = 0.f;
+    if (j < L) {
+        const int p = j + NF / 2;
+        int hi = p / HOPF; if (hi > T - 1) hi = T - 1;
+        int lo = (p - NF + HOPF) / HOPF; if (p - NF + 1 <= 0) lo = 0;
+        float s = 0.f;
+        for (int t = lo; t <= hi; ++t) s += frames[((size_t)b * T + t) * NF + (p - t * HOPF)];
+        s /= (float)(hi - lo + 1);
+        audio[(size_t)b * L + j] = s;
+        if (clean) ad = fabsf(s - clean[(size_t)b * L + j]);
+    }
+    if (l1_partials) {
+        double r = block_sum_f64((double)ad, red);
+        if (threadIdx.x == 0) l1_partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (float)r;
+    }
+}
+
+// g_audio[i] = scale[0] * sign(den - clean)   (gradient of mean |den - clean|, scale = upstream/(B L))
+__global__ void l1_grad_kernel(const float* __restrict__ den, const float* __restrict__ clean,
+                               const float* __restrict__ scale, float* __restrict__ g, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float d = den[i] - clean[i];
+    g[i] = (d > 0.f) ? scale[0] : ((d < 0.f) ? -scale[0] : 0.f);
+}
+
+// backward of mask + iSTFT: g_audio (B, L) -> g_net (B*T, 8, 257)
+__global__ __launch_bounds__(256) void mask_istft_bwd_kernel(const float* __restrict__ g_audio,
+                                                             const float* __restrict__ net_out,
+                                                             float* __restrict__ g_net, const cpx* __restrict__ tw,
+                                                             int T, int L, float beta) {
+    __shared__ cpx sa[NF], sb[NF];
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * 2;
+    for (int i = threadIdx.x; i < NF; i += 256) {
+        float v[2] = {0.f, 0.f};
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int t = t0 + f;
+            const int p = t * HOPF + i;
+            const int j = p - NF / 2;
+            if (t < T && j >= 0 && j < L) v[f] = g_audio[(size_t)b * L + j] / ola_env(p, T);
+        }
+        sa[i] = make_float2(v[0], v[1]);
+    }
+    const cpx* Z = fft_lds(sa, sb, NF, 9, tw, false);
+    for (int k = threadIdx.x; k < BINS; k += 256) {
+        cpx G[2];
+        split_pair(Z, k, NF, G[0], G[1]);
+        const float wk = (k == 0 || k == NF / 2) ? (1.f / NF) : (2.f / NF);
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int t = t0 + f;
+            if (t >= T) continue;
+            const size_t base = (size_t)(b * T + t) * 8 * BINS + k;
+            const float* o = net_out + base;
+            const MaskVals v = mask_vals(o, BINS, beta);
+            const float dRe = wk * G[f].x;
+            const float dIm = (k == 0 || k == NF / 2) ? 0.f : wk * G[f].y;
+            const float M = v.S * v.A;
+            const float dM = dRe * v.cm + dIm * v.sm;
+            float dpm = M * (dIm * v.cm - dRe * v.sm);
+            const float du = dM * v.A * v.S * (1.f - v.S);
+            dpm += beta * du;
+            const float dpn = -beta * du;
+            const float dA = dM * v.S;
+            const float dc0 = (v.c0 >= -1.f && v.c0 <= 1.f) ? dA * v.A * 2.5f * 2.302585092994046f : 0.f;
+            const float c2 = o[2 * BINS], c3 = o[3 * BINS], c6 = o[6 * BINS], c7 = o[7 * BINS];
+            float* g = g_net + base;
+            g[0] = dc0;
+            g[1 * BINS] = 0.f;
+            g[2 * BINS] = (v.r2m > 0.f) ? dpm * c3 / v.r2m : 0.f;
+            g[3 * BINS] = (v.r2m > 0.f) ? -dpm * c2 / v.r2m : 0.f;
+            g[4 * BINS] = 0.f;
+            g[5 * BINS] = 0.f;
+            g[6 * BINS] = (v.r2n > 0.f) ? dpn * c7 / v.r2n : 0.f;
+            g[7 * BINS] = (v.r2n > 0.f) ? -dpn * c6 / v.r2n : 0.f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- multi-resolution STFT loss
+// one block per (frame f, signal b): z = w*x + j w*y -> FFT -> |X|, |Y| -> three sums
+__global__ __launch_bounds__(256) void stft_loss_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                            const float* __restrict__ win, const cpx* __restrict__ tw,
+                                                            float* __restrict__ partials, int L, int n, int logn, int hop,
+                                                            int nframes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    cpx* sa = (cpx*)smraw;
+    cpx* sb = sa + n;
+    __shared__ double red[256];
+    const int f = blockIdx.x, b = blockIdx.y;
+    const float* xb = x + (size_t)b * L;
+    const float* yb = y + (size_t)b * L;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int j = reflect_idx(f * hop + i - n / 2, L);
+        const float w = win[i];
+        sa[i] = make_float2(w * xb[j], w * yb[j]);
+    }
+    const cpx* Z = fft_lds(sa, sb, n, logn, tw, false);
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int k = threadIdx.x; k <= n / 2; k += 256) {
+        cpx X, Y;
+        split_pair(Z, k, n, X, Y);
+        const float xm = sqrtf(fmaxf(X.x * X.x + X.y * X.y, 1e-7f));   // stft_loss.py:30
+        const float ym = sqrtf(fmaxf(Y.x * Y.x + Y.y * Y.y, 1e-7f));
+        const float d = ym - xm;
+        s1 = fmaf(d, d, s1);
+        s2 = fmaf(ym, ym, s2);
+        s3 += fabsf(logf(ym) - logf(xm));
+    }
+    double r;
+    float* pp = partials + ((size_t)b * nframes + f) * 3;
+    r = block_sum_f64((double)s1, red); if (threadIdx.x == 0) pp[0] = (float)r;
+    r = block_sum_f64((double)s2, red); if (threadIdx.x == 0) pp[1] = (float)r;
+    r = block_sum_f64((double)s3, red); if (threadIdx.x == 0) pp[2] = (float)r;
+}
+
+// out[c] = sum_g partials[g*ncols + c], one block per column, fp64
+__global__ __launch_bounds__(256) void reduce_cols_kernel(const float* __restrict__ partials, int nparts, int ncols,
+                                                          float* __restrict__ out) {
+    __shared__ double red[256];
+    const int c = blockIdx.x;
+    double s = 0.0;
+    for (int g = threadIdx.x; g < nparts; g += 256) s += (double)partials[(size_t)g * ncols + c];
+    s = block_sum_f64(s, red);
+    if (threadIdx.x == 0) out[c] = (float)s;
+}
+
+// backward: coef[0] = d loss / d(sum (ym-xm)^2 -> sc) prefactor, see host; per bin
+//   g_xm = coef[0] * (xm - ym) + coef[1] * sign(log xm - log ym) / xm
+// with coef[0] = g_sc * lam_sc / (nres * sqrt(S1) * sqrt(S2)), coef[1] = g_mag * lam_mag / (nres * count)
+__global__ __launch_bounds__(256) void stft_loss_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                            const float* __restrict__ win, const cpx* __restrict__ tw,
+                                                            const float* __restrict__ coef, float* __restrict__ gx, int L,
+                                                            int n, int logn, int hop) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    cpx* sa = (cpx*)smraw;
+    cpx* sb = sa + n;
+    const int f = blockIdx.x, b = blockIdx.y;
+    const float* xb = x + (size_t)b * L;
+    const float* yb = y + (size_t)b * L;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int j = reflect_idx(f * hop + i - n / 2, L);
+        const float w = win[i];
+        sa[i] = make_float2(w * xb[j], w * yb[j]);
+    }
+    cpx* Z = fft_lds(sa, sb, n, logn, tw, false);
+    cpx* other = (Z == sa) ? sb : sa;
+    const float c_sc = coef[0], c_mag = coef[1];
+    // build the half spectrum of gradients in `other` (upper half zero), then inverse FFT, real part
+    for (int k = threadIdx.x; k < n; k += 256) {
+        cpx G = make_float2(0.f, 0.f);
+        if (k <= n / 2) {
+            cpx X, Y;
+            split_pair(Z, k, n, X, Y);
+            const float px = X.x * X.x + X.y * X.y;
+            if (px > 1e-7f) {   // clamp(min=1e-7) passes no gradient below the floor
+                const float xm = sqrtf(px);
+                const float ym = sqrtf(fmaxf(Y.x * Y.x + Y.y * Y.y, 1e-7f));
+                const float dl = logf(xm) - logf(ym);
+                const float sg = (dl > 0.f) ? 1.f : ((dl < 0.f) ? -1.f : 0.f);
+                const float gm = c_sc * (xm - ym) + c_mag * sg / xm;
+                G = make_float2(gm * X.x / xm, gm * X.y / xm);
+            }
+        }
+        other[k] = G;
+    }
+    const cpx* g = fft_lds(other, Z, n, logn, tw, true);
+    float* gb = gx + (size_t)b * L;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float w = win[i];
+        if (w != 0.f) {
+            const int j = reflect_idx(f * hop + i - n / 2, L);
+            atomicAdd(gb + j, w * g[i].x);
+        }
+    }
+}
+
+__global__ void phm_kernel(const float2* __restrict__ m, const float2* __restrict__ e, float* __restrict__ out,
+                           int64_t n, float beta) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float2 a = m[i], b = e[i];
+    const float d = atan2f(a.y, a.x) - atan2f(b.y, b.x);
+    out[i] = sqrtf(a.x * a.x + a.y * a.y) / (1.f + expf(-beta * d));
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int trunet_stft_features(const float* audio, float* feat, float* mag, const float* tw512, int B, int L, int T,
+                                    int C, void* stream) {
+    if (!audio || !feat || !tw512 || B <= 0 || L < NF / 2 + 1 || T != 1 + L / HOPF || (C != 3 && C != 4)) return TRUNET_EINVAL;
+    hipLaunchKernelGGL(stft_features_kernel, dim3((T + 1) / 2, B), dim3(256), 0, ST, audio, feat, mag, (const cpx*)tw512, L, T, C);
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_pcen(const float* mag, float* out, int B, int T, int out_stride, float eps, float s, float alpha,
+                           float delta, float r, void* stream) {
+    if (!mag || !out || B <= 0 || T <= 0) return TRUNET_EINVAL;
+    hipLaunchKernelGGL(pcen_kernel, dim3((BINS + 63) / 64, B), dim3(64), 0, ST, mag, out, T, out_stride, eps, s, alpha, delta, r);
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_mask_istft_fwd(const float* net_out, float* frames, float* audio, const float* clean,
+                                     float* l1_partials, const float* tw512, int B, int T, int L, float beta, void* stream) {
+    if (!net_out || !frames || !audio || !tw512 || B <= 0 || T < 2 || L != (T - 1) * HOPF) return TRUNET_EINVAL;
+    hipLaunchKernelGGL(mask_istft_frames_kernel, dim3((T + 1) / 2, B), dim3(256), 0, ST, net_out, frames, (const cpx*)tw512, T, beta);
+    hipLaunchKernelGGL(ola_kernel, dim3((L + 255) / 256, B), dim3(256), 0, ST, frames, audio, clean, l1_partials, T, L);
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_mask_istft_l1_nparts(int B, int L) { return B * ((L + 255) / 256); }
+
+extern "C" int trunet_mask_istft_bwd(const float* g_audio, const float* net_out, float* g_net, const float* tw512, int B,
+                                     int T, int L, float beta, void* stream) {
+    if (!g_audio || !net_out || !g_net || !tw512 || B <= 0 || T < 2 || L != (T - 1) * HOPF) return TRUNET_EINVAL;
+    hipLaunchKernelGGL(mask_istft_bwd_kernel, dim3((T + 1) / 2, B), dim3(256), 0, ST, g_audio, net_out, g_net, (const cpx*)tw512, T, L, beta);
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_l1_grad(const float* den, const float* clean, const float* scale, float* g, int64_t n, void* stream) {
+    if (!den || !clean || !scale || !g || n <= 0) return TRUNET_EINVAL;
+    hipLaunchKernelGGL(l1_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ST, den, clean, scale, g, n);
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_reduce_cols(const float* partials, int nparts, int ncols, float* out, void* stream) {
+    if (!partials || !out || nparts <= 0 || ncols <= 0) return TRUNET_EINVAL;
+    hipLaunchKernelGGL(reduce_cols_kernel, dim3(ncols), dim3(256), 0, ST, partials, nparts, ncols, out);
+    return trunet_launch_status();
+}
+
+static int ilog2(int n) { int l = 0; while ((1 << l) < n) ++l; return ((1 << l) == n) ? l : -1; }
+
+extern "C" int trunet_stft_loss_fwd(const float* x, const float* y, const float* win, const float* tw, float* partials,
+                                    int B, int L, int n, int hop, void* stream) {
+    const int logn = ilog2(n);
+    if (!x || !y || !win || !tw || !partials || B <= 0 || logn < 3 || n > 4096 || hop <= 0 || L <= n / 2) return TRUNET_EINVAL;
+    const int nframes = 1 + L / hop;
+    hipLaunchKernelGGL(stft_loss_fwd_kernel, dim3(nframes, B), dim3(256), 2 * n * sizeof(cpx), ST, x, y, win, (const cpx*)tw,
+                       partials, L, n, logn, hop, nframes);
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_stft_loss_bwd(const float* x, const float* y, const float* win, const float* tw, const float* coef,
+                                    float* gx, int B, int L, int n, int hop, void* stream) {
+    const int logn = ilog2(n);
+    if (!x || !y || !win || !tw || !coef || !gx || B <= 0 || logn < 3 || n > 4096 || hop <= 0 || L <= n / 2) return TRUNET_EINVAL;
+    const int nframes = 1 + L / hop;
+    hipLaunchKernelGGL(stft_loss_bwd_kernel, dim3(nframes, B), dim3(256), 2 * n * sizeof(cpx), ST, x, y, win, (const cpx*)tw,
+                       coef, gx, L, n, logn, hop);
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_phm_fwd(const float* mix_ri, const float* est_ri, float* out, int64_t n, float beta, void* stream) {
+    if (!mix_ri || !est_ri || !out || n <= 0) return TRUNET_EINVAL;
+    hipLaunchKernelGGL(phm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ST, (const float2*)mix_ri,
+                       (const float2*)est_ri, out, n, beta);
+    return trunet_launch_status();
+}

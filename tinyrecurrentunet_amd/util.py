@@ -1,0 +1,175 @@
+"""MI355X-native ``util``: the train-step composition ``loss_fn`` (``/root/reference/util.py:186-251`` in the
+repaired form R7 of SURVEY.md section 0.2), the LR schedule (``util.py:81-156``) and the small host helpers
+``train.py`` imports (``find_max_epoch`` :30-49, ``print_size`` :52-61, ``rescale`` :26-27).
+
+loss_fn: features(noisy) [HIP STFT] -> net [HIP body] -> phase-aware mask + iSTFT [HIP] ->
+L1(audio, clean) + stft_lambda * (sc + mag) [HIP multi-resolution STFT loss]; every stage has a hand-written
+backward, chained through ``torch.autograd.Function`` nodes (autograd is glue only)."""
+import os
+from math import cos, pi
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import dataset as ds
+from ._lib import check, ptr
+
+BINS, N_FFT, HOP = 257, 512, 128
+
+
+class _MaskISTFTL1Fn(torch.autograd.Function):
+    """net output (B*T, 8, 257), clean (B, L) -> denoised audio (B, L), l1 = mean |audio - clean|."""
+
+    @staticmethod
+    def forward(ctx, net_out, clean, T, beta):
+        net_out = net_out.contiguous()
+        B = net_out.shape[0] // T
+        Ln = (T - 1) * HOP
+        dev = net_out.device
+        lib = L.lib()
+        frames = torch.empty((B, T, N_FFT), device=dev, dtype=torch.float32)
+        audio = torch.empty((B, Ln), device=dev, dtype=torch.float32)
+        npart = lib.trunet_mask_istft_l1_nparts(B, Ln)
+        part = torch.empty(npart, device=dev, dtype=torch.float32)
+        tw = L.twiddles(N_FFT, dev)
+        check(lib.trunet_mask_istft_fwd(ptr(net_out), ptr(frames), ptr(audio), ptr(clean), ptr(part), ptr(tw), B, T,
+                                        Ln, beta, L.stream()), "mask_istft_fwd")
+        s = torch.empty(1, device=dev, dtype=torch.float32)
+        check(lib.trunet_reduce_cols(ptr(part), npart, 1, ptr(s), L.stream()), "reduce_cols")
+        l1 = s[0] / float(B * Ln)
+        ctx.save_for_backward(net_out, clean, audio, tw)
+        ctx.T, ctx.beta = T, beta
+        return audio, l1
+
+    @staticmethod
+    def backward(ctx, g_audio, g_l1):
+        net_out, clean, audio, tw = ctx.saved_tensors
+        T = ctx.T
+        B, Ln = audio.shape
+        lib = L.lib()
+        if g_l1 is None:
+            g_l1 = torch.zeros((), device=audio.device)
+        scale = (g_l1 / float(B * Ln)).reshape(1).float().contiguous()
+        g = torch.empty_like(audio)
+        check(lib.trunet_l1_grad(ptr(audio), ptr(clean), ptr(scale), ptr(g), audio.numel(), L.stream()), "l1_grad")
+        if g_audio is not None:
+            g = g + g_audio
+        g_net = torch.empty_like(net_out)
+        check(lib.trunet_mask_istft_bwd(ptr(g.contiguous()), ptr(net_out), ptr(g_net), ptr(tw), B, T, Ln, ctx.beta,
+                                        L.stream()), "mask_istft_bwd")
+        return g_net, None, None, None
+
+
+def denoise(net_out, clean_BL, T, beta=0.5):
+    """R7: (B*T, 8, 257) -> (audio (B, L), l1)."""
+    return _MaskISTFTL1Fn.apply(net_out, clean_BL.contiguous().float(), T, float(beta))
+
+
+def loss_fn(net, X, ell_p, ell_p_lambda, stft_lambda, mrstftloss, pcen=None, **kwargs):
+    """util.py:186-251 (R7).  X = (clean_audio, noisy_audio), each (B, 1, L) (a leading batch-1 dim as the
+    reference's DataLoader gives, util.py:207, is squeezed).  Returns (loss, {"l1", "stft_sc", "stft_mag"})."""
+    clean_audio, noisy_audio = X
+    if clean_audio.dim() == 4:
+        clean_audio, noisy_audio = clean_audio.squeeze(0), noisy_audio.squeeze(0)
+    clean = clean_audio[:, 0].contiguous()
+    noisy = noisy_audio[:, 0].contiguous()
+    if pcen is None:
+        pcen = net.encoder[0].StandardConv1d[0].in_channels == 4
+    feats = ds.stft_features(noisy, pcen=pcen)
+    T = feats.shape[0] // noisy.shape[0]
+    out = net(feats)
+    den, l1 = denoise(out, clean, T)
+    l1 = torch.abs(l1)
+    loss = l1 * ell_p_lambda
+    output_dic = {"l1": l1.detach()}
+    if stft_lambda > 0:
+        sc_loss, mag_loss = mrstftloss(den, clean)
+        loss = loss + (sc_loss + mag_loss) * stft_lambda
+        output_dic["stft_sc"] = sc_loss.detach() * stft_lambda
+        output_dic["stft_mag"] = mag_loss.detach() * stft_lambda
+    return loss, output_dic
+
+
+# ----------------------------------------------------------------------------- LR schedule (util.py:81-156)
+def anneal_linear(start, end, proportion):
+    return start + proportion * (end - start)
+
+
+def anneal_cosine(start, end, proportion):
+    return end + (start - end) / 2 * (cos(pi * proportion) + 1)
+
+
+class Phase:
+    def __init__(self, start, end, n_iter, cur_iter, anneal_fn):
+        self.start, self.end, self.n_iter, self.anneal_fn, self.n = start, end, n_iter, anneal_fn, cur_iter
+
+    def step(self):
+        self.n += 1
+        return self.anneal_fn(self.start, self.end, self.n / self.n_iter)
+
+    def reset(self):
+        self.n = 0
+
+    @property
+    def is_done(self):
+        return self.n >= self.n_iter
+
+
+class LinearWarmupCosineDecay:
+    """util.py:110-156: linear warm-up lr_max/divider -> lr_max, cosine decay to lr_max/divider/1e4."""
+
+    def __init__(self, optimizer, lr_max, n_iter, iteration=0, divider=25, warmup_proportion=0.3,
+                 phase=("linear", "cosine")):
+        self.optimizer = optimizer
+        phase1 = int(n_iter * warmup_proportion)
+        phase2 = n_iter - phase1
+        lr_min = lr_max / divider
+        fns = {"linear": anneal_linear, "cosine": anneal_cosine}
+        self.lr_phase = [Phase(lr_min, lr_max, phase1, iteration, fns[phase[0]]),
+                         Phase(lr_max, lr_min / 1e4, phase2, max(0, iteration - phase1), fns[phase[1]])]
+        self.phase = 0 if iteration < phase1 else 1
+
+    def step(self):
+        lr = self.lr_phase[self.phase].step()
+        for group in self.optimizer.param_groups:
+            group["lr"] = lr
+        if self.lr_phase[self.phase].is_done:
+            self.phase += 1
+        if self.phase >= len(self.lr_phase):
+            for ph in self.lr_phase:
+                ph.reset()
+            self.phase = 0
+        return lr
+
+
+# ----------------------------------------------------------------------------- small host helpers
+def rescale(x):
+    return (x - x.min()) / (x.max() - x.min())
+
+
+def find_max_epoch(path):
+    """util.py:30-49: largest <iter>.pkl in ``path`` or -1."""
+    epoch = -1
+    for f in os.listdir(path):
+        if len(f) > 4 and f[-4:] == ".pkl":
+            try:
+                epoch = max(epoch, int(f[:-4]))
+            except ValueError:
+                continue
+    return epoch
+
+
+def print_size(net, keyword=None):
+    """util.py:52-61."""
+    if net is not None and isinstance(net, torch.nn.Module):
+        params = sum(np.prod(p.size()) for p in net.parameters() if p.requires_grad)
+        print("{} Parameters: {:.6f}M".format(net.__class__.__name__, params / 1e6), flush=True, end="; ")
+        if keyword is not None:
+            print(keyword, end="; ")
+        print(" ")
+
+
+@torch.no_grad()
+def sampling(net, noisy_features):
+    return net(noisy_features)
