@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 16 kHz frames/sec of a full TRU-Net train step (BASELINE.json configs[1]).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = train.py:128-140 of the reference: zero_grad -> STFT features (+PCEN) -> TRU-Net -> phase-aware mask ->
+iSTFT -> L1 + multi-resolution STFT loss -> backward -> gradient all-reduce (N>1) -> grad-norm -> LR schedule ->
+AdamW, on synthetic 64 x 4 s 16 kHz pairs per GPU (weak scaling), fp32, inputs resident in HBM.
+Prints ONE JSON line (rank 0) with the `roofline` and `cpu_baseline` objects described in DESIGN.md.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+STFT_CFG = dict(fft_sizes=[512, 1024, 2048], hop_sizes=[50, 120, 240], win_lengths=[240, 600, 1200],
+                sc_lambda=0.5, mag_lambda=0.5, band="full")
+FLOPS_PER_FRAME_STEP = 94089216       # 3 x 31,363,072 (C_in = 4)
+PEAK_F32_TFLOPS = 157.3               # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
+HBM_BYTES_PER_FRAME_STEP = 2462912    # SURVEY 8d (ii) layer-boundary model
+
+
+def synth(B, L, seed, device):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    c = 0.1 * torch.randn((B, 1, L + 1), generator=g, device=device)
+    clean = 0.5 * (c[..., 1:] + c[..., :-1])
+    noisy = clean + 0.05 * torch.randn((B, 1, L), generator=g, device=device)
+    return clean.contiguous(), noisy.contiguous()
+
+
+def usable_cores():
+    """Cores this process may really use: affinity mask, cgroup CPU quota, and the GPU box's per-GPU CPU share
+    (16) -- more threads than that oversubscribe the container and make the torch CPU path crawl."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(B=4, L=64000, steps=3):
+    """The reference's CPU path = the oracle (same stock torch.nn / torch.stft calls in the same order,
+    SURVEY 8d), timed on this host's cores on a bounded sample of the same workload."""
+    from oracle import loss_ref, network_ref as nr
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    net = nr.TRUNet(input_size=4).train()
+    opt = torch.optim.AdamW(net.parameters(), lr=4e-4)
+    clean, noisy = synth(B, L, 1234, "cpu")
+    T = 1 + L // 128
+    times = []
+    for it in range(steps + 1):
+        t0 = time.time()
+        opt.zero_grad()
+        loss, _, _ = loss_ref.loss_fn(net, clean, noisy, stft_config=STFT_CFG, pcen=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), 1e9)
+        opt.step()
+        times.append(time.time() - t0)
+        print("[cpu_baseline] step %d: %.2f s on %d threads" % (it, times[-1], cores), file=sys.stderr, flush=True)
+        if it >= 1 and sum(times) > 60:
+            break
+    dt = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": B * T / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "B=%dx4s (%d frames) train step, median of %d after 1 warm-up, torch %s CPU" % (
+                B, B * T, len(times) - 1, torch.__version__)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
+    ap.add_argument("--seconds", type=float, default=4.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stft-loss", action="store_true", help="ablation (BASELINE.json configs[4])")
+    ap.add_argument("--no-pcen", action="store_true", help="ablation (BASELINE.json configs[4])")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from tinyrecurrentunet_amd import distributed as tdist, engine, network as hn, optim, stft_loss as sl, util
+    cin = 3 if args.no_pcen else 4
+    torch.manual_seed(0)                      # train.py:12-14
+    net = hn.TRUNet(input_size=cin).to(dev).train()
+    if world > 1:
+        tdist.apply_gradient_allreduce(net)
+    opt = optim.FusedAdamW(net.parameters(), lr=4e-4)
+    sched = util.LinearWarmupCosineDecay(opt, lr_max=4e-4, n_iter=25000000, iteration=0, divider=25,
+                                         warmup_proportion=0.05, phase=("linear", "cosine"))
+    mr = sl.MultiResolutionSTFTLoss(**STFT_CFG).to(dev)
+    L = int(args.seconds * 16000)
+    clean, noisy = synth(args.batch, L, 1234 + rank, dev)
+    T = 1 + L // 128
+    frames = args.batch * T
+    stft_lambda = 0 if args.no_stft_loss else 1
+
+    def step():
+        opt.zero_grad()
+        loss, info = util.loss_fn(net, (clean, noisy), ell_p=1, ell_p_lambda=1, stft_lambda=stft_lambda,
+                                  mrstftloss=mr if stft_lambda else None)
+        loss.backward()                        # all-reduce fires inside (N > 1)
+        sched.step()
+        nsq = opt.step()                       # fused grad-norm + AdamW
+        return loss, nsq
+
+    for _ in range(args.warmup):
+        step()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sync()
+    t0 = time.time()
+    for _ in range(args.steps):
+        loss, nsq = step()
+    sync()
+    dt = time.time() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    ms = dt / args.steps * 1e3
+    total_frames = frames * world
+    value = total_frames / (dt / args.steps)
+
+    roof = None
+    if rank == 0:
+        # per-kernel timing of one more step with HIP events on the launch stream (torch's current stream)
+        engine.PROFILE = prof = {}
+        step()
+        torch.cuda.synchronize()
+        engine.PROFILE = None
+        agg = {}
+        for name, recs in prof.items():
+            tot_ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+            agg[name] = (tot_ms, sum(f for _, _, f in recs), len(recs))
+        name = max(agg, key=lambda k: agg[k][0])
+        tot_ms, flops, n = agg[name]
+        ach = flops / (tot_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": None,
+                "launches_per_step": n, "avg_launch_ms": round(tot_ms / n, 4),
+                "kernel_ms_per_step": {k: round(v[0], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])},
+                "step_flop_frac_of_peak": round(value / world * FLOPS_PER_FRAME_STEP / 1e12 / PEAK_F32_TFLOPS, 4),
+                "step_hbm_GBps_layer_model": round(value / world * HBM_BYTES_PER_FRAME_STEP / 1e9, 1)}
+    if rank == 0:
+        cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()
+        out = {"metric": "16 kHz frames/sec (train step)", "value": round(value, 1), "unit": "frames/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic",
+               "config": {"workload": "config/tiny.json TRU-Net (C_in=%d%s), %d x %.0f s 16 kHz pairs per GPU, "
+                                      "n_fft 512 hop 128, full fp32 train step%s" % (
+                                          cin, " incl. PCEN" if cin == 4 else "", args.batch, args.seconds,
+                                          "" if stft_lambda else " WITHOUT MR-STFT loss"),
+                          "frames_per_gpu": frames, "global_batch": args.batch * world,
+                          "parallelism": "dp%d" % world, "loss": float(loss)},
+               "roofline": roof, "cpu_baseline": cpu}
+        if cpu:
+            out["gpu_over_cpu"] = round(value / cpu["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

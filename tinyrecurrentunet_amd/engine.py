@@ -21,6 +21,48 @@ BN_EPS = 1e-5
 BN_MOM = 0.1
 
 
+# bench.py sets this to a dict to time kernels with HIP events on the launch stream:
+# PROFILE[kernel] = [(start_event, end_event, algorithmic_flops), ...]
+PROFILE = None
+
+
+class _Timed:
+    def __init__(self, name, flops=0.0):
+        self.name, self.flops = name, flops
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            self.b.record()
+            PROFILE.setdefault(self.name, []).append((self.a, self.b, self.flops))
+        return False
+
+
+def _gemm_rs(M, segs):
+    """Mirror of pick_rs() in gemm_conv.hip (which template instance a launch uses)."""
+    nck = sum((s.nchan + 31) // 32 for s in segs)
+    rs = 4 if M > 64 else (2 if M > 32 else 1)
+    while rs > 1 and nck * rs * 4096 > 112 * 1024:
+        rs >>= 1
+    return rs
+
+
+def _seg_positions(s, p0, P):
+    """number of output positions p in [p0, p0+P) for which segment s is valid"""
+    n = 0
+    for p in range(p0, p0 + P):
+        qn = p * s.pos_mul + s.pos_off
+        if qn >= 0 and qn % s.pos_div == 0 and qn // s.pos_div < s.L:
+            n += 1
+    return n
+
+
 def ceil_to(n, m):
     return (n + m - 1) // m * m
 
@@ -120,6 +162,11 @@ class TRUNetEngine:
             part = w.flat("partials", nparts * stats * 2)
             a.partials, a.M_stat = ptr(part), stats
         a.epi = epi
+        if PROFILE is not None:
+            fl = 2.0 * N * M * sum(s.nchan * _seg_positions(s, p_begin, P) for s in segs)
+            with _Timed("conv_gemm_kernel<%d>" % _gemm_rs(M, segs), fl):
+                check(L.lib().trunet_conv_gemm(a, L.stream()), "conv_gemm")
+            return nparts
         check(L.lib().trunet_conv_gemm(a, L.stream()), "conv_gemm")
         return nparts
 
@@ -297,7 +344,12 @@ class TRUNetEngine:
         bp = w.flat("b_partials", nparts * 512)
         a.b_partials = ptr(bp)
         a.b_stride, a.b_off = bt, b_off
-        check(lib.trunet_conv_wgrad(a, L.stream()), "conv_wgrad")
+        if PROFILE is not None:
+            fl = 2.0 * N * M * sum(s.nchan * _seg_positions(s, 0, P) for s in segs)
+            with _Timed("conv_wgrad_kernel", fl):
+                check(lib.trunet_conv_wgrad(a, L.stream()), "conv_wgrad")
+        else:
+            check(lib.trunet_conv_wgrad(a, L.stream()), "conv_wgrad")
         if reduce:
             gw = wgrad_out if wgrad_out is not None else torch.empty_like(W)
             check(lib.trunet_reduce_partials(ptr(gw), ptr(wp), nparts, numel, 0, L.stream()), "reduce")
