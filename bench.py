@@ -160,9 +160,17 @@ def main():
     if rank == 0:
         # per-kernel timing of one more step with HIP events on the launch stream (torch's current stream)
         engine.PROFILE = prof = {}
+        if os.environ.get("TRUNET_BENCH_LAUNCH_LOG"):
+            engine.PROFILE_LOG = []
         step()
         torch.cuda.synchronize()
         engine.PROFILE = None
+        if engine.PROFILE_LOG is not None:
+            with open(os.environ["TRUNET_BENCH_LAUNCH_LOG"], "w") as f:
+                for nm, tag, ea, eb, fl in engine.PROFILE_LOG:
+                    ms_ = ea.elapsed_time(eb)
+                    f.write("%-22s %-28s %8.3f ms %7.1f TF\n" % (nm, tag, ms_, fl / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0))
+            engine.PROFILE_LOG = None
         agg = {}
         for name, recs in prof.items():
             tot_ms = sum(a.elapsed_time(b) for a, b, _ in recs)

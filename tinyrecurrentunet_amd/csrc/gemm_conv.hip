@@ -19,7 +19,6 @@
 namespace {
 
 constexpr int NT = TRUNET_TILE_FRAMES;  // frames per tile
-constexpr int KC = 32;                  // K rows per staged chunk
 
 template <int CT>
 struct BVec;
@@ -49,11 +48,85 @@ __device__ __forceinline__ SegPos seg_pos(const trunet_seg& sg, int p) {
     return r;
 }
 
-template <int RS>
-__global__ __launch_bounds__(256, 1) void conv_gemm_kernel(const trunet_gemm_args a) {
+// position in the flattened stream of K-chunks this workgroup walks: tiles in a contiguous range,
+// inside a tile the valid segments in order, inside a segment its KC-row chunks
+struct ChunkIt {
+    int tile, tile_end, p, n0, s, cc, ach, cbase;
+    bool valid;
+};
+
+template <int KC>
+__device__ __forceinline__ void it_enter_tile(const trunet_gemm_args& a, ChunkIt& it) {
+    it.valid = it.tile < it.tile_end;
+    if (!it.valid) return;
+    const int nt = it.tile / a.P;
+    it.p = a.p_begin + (it.tile - nt * a.P);
+    it.n0 = nt * NT;
+    it.s = 0; it.cc = 0; it.ach = 0; it.cbase = 0;
+    while (it.s < a.nseg - 1 && !seg_pos(a.seg[it.s], it.p).valid) {   // host contract: >= 1 valid segment
+        it.ach += (a.seg[it.s].nchan + KC - 1) / KC;
+        it.cbase += a.seg[it.s].nchan;
+        ++it.s;
+    }
+}
+
+// true when the chunk after `it` belongs to another tile (or the stream ends)
+template <int KC>
+__device__ __forceinline__ bool it_next(const trunet_gemm_args& a, ChunkIt& it) {
+    const int nck = (a.seg[it.s].nchan + KC - 1) / KC;
+    if (++it.cc < nck) return false;
+    it.ach += nck;
+    it.cbase += a.seg[it.s].nchan;
+    it.cc = 0;
+    ++it.s;
+    while (it.s < a.nseg && !seg_pos(a.seg[it.s], it.p).valid) {
+        it.ach += (a.seg[it.s].nchan + KC - 1) / KC;
+        it.cbase += a.seg[it.s].nchan;
+        ++it.s;
+    }
+    if (it.s < a.nseg) return false;
+    ++it.tile;
+    it_enter_tile<KC>(a, it);
+    return true;
+}
+
+__device__ __forceinline__ void wait_vmcnt(int n) {   // n = LDS-DMA instructions allowed to stay in flight
+    switch (n >> 2) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(44)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+    }
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// RS: 32-row slices of the M block (wave tiling, see header).  KC: K rows per chunk.  TWO: the operand is
+// c0*src0 + c1*src1 + c2 (BatchNorm backward) instead of max(c0*src0 + c1, lo).  EPL: epilogue tensor
+// loads (0 none, 1 zmask, 2 zmask + previous output).
+//
+// Pipeline per K-chunk (ring of NB LDS slots, chunk j in slot j % NB):
+//   LDS-DMA (global_load_lds, issued NB chunks ahead, no VGPRs)  ->  in-place prologue pass by the thread that
+//   issued the DMA (one chunk ahead of the MFMAs)  ->  fragment reads + MFMAs.  One raw s_barrier per chunk;
+//   DMA completion is tracked with counted s_waitcnt vmcnt, so NB-1 chunks (16 KiB each) stay in flight.
+template <int RS, int KC, bool TWO, int EPL>
+__global__ __launch_bounds__(256, 1) void conv_gemm_kernel(const trunet_gemm_args a, const int NB) {
     constexpr int CT = RS;            // column tiles (of 32 frames) per wave
     constexpr int CG = 4 / RS;        // column groups
     constexpr int MB = 32 * RS;       // rows per M block
+    constexpr int KP = KC / 2;        // k-pairs per chunk
+    constexpr int NSRC = TWO ? 2 : 1;
+    constexpr int CHF = KC * NT * NSRC;            // floats per ring slot
+    constexpr int LPW = (KC / 8) * NSRC;           // DMA instructions per wave per chunk
     typedef typename BVec<CT>::type bvec;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -66,195 +139,245 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_kernel(const trunet_gemm_arg
     const int c = lane & 31;
     const int mblk = blockIdx.y;
 
-    // chunk prefix per segment (uniform)
-    int nck_total = 0;
-    for (int s = 0; s < a.nseg; ++s) nck_total += (a.seg[s].nchan + KC - 1) / KC;
+    int nck_total = 0, nchan_total = 0;
+    for (int s = 0; s < a.nseg; ++s) {
+        nck_total += (a.seg[s].nchan + KC - 1) / KC;
+        nchan_total += a.seg[s].nchan;
+    }
+    // LDS carve (one array): A fragments | ring | prologue coefficients (float4 per channel) | epilogue rows
     float* A_lds = smem;
-    float* B_lds = smem + (size_t)nck_total * RS * 1024;
+    float* R_lds = A_lds + (size_t)nck_total * RS * (KP * 64);
+    f32x4* C_lds = (f32x4*)(R_lds + (size_t)NB * CHF);
+    float* E_lds = (float*)(C_lds + nchan_total);
 
     const int ntn = a.NP / NT;
     const int total_tiles = a.P * ntn;
-
-    // ---- load the weight block into LDS in fragment order: [chunk][rs][kg][lane][4]
-    if ((int)blockIdx.x < total_tiles) {
-        const int totalA = nck_total * RS * 1024;
-        for (int idx = tid; idx < totalA; idx += 256) {
-            int j = idx & 3;
-            int ln = (idx >> 2) & 63;
-            int kg = (idx >> 8) & 3;
-            int rest = idx >> 10;
-            int rr = rest % RS;
-            int ch = rest / RS;
-            int s = 0, cc = ch;
-            while (cc >= (a.seg[s].nchan + KC - 1) / KC) { cc -= (a.seg[s].nchan + KC - 1) / KC; ++s; }
-            int kk = 4 * kg + j;
-            int ci = cc * KC + 2 * kk + (ln >> 5);
-            int m = mblk * MB + 32 * rr + (ln & 31);
-            float v = 0.f;
-            if (ci < a.seg[s].nchan && m < a.M)
-                v = a.W[(size_t)(m + a.w_m_off) * a.ldw_m + (size_t)ci * a.ldw_c + a.seg[s].woff];
-            A_lds[idx] = v;
-        }
-    }
-    __syncthreads();
+    ChunkIt cur;
+    cur.tile = (int)(((long long)blockIdx.x * total_tiles) / gridDim.x);
+    cur.tile_end = (int)(((long long)(blockIdx.x + 1) * total_tiles) / gridDim.x);
+    const bool has_work = cur.tile < cur.tile_end;
 
     float st1[16], st2[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { st1[r] = 0.f; st2[r] = 0.f; }
 
-    const int srow = tid >> 5;       // staging: row within chunk = srow + 8*i
-    const int sf4 = tid & 31;        // staging: float4 index within the 128-frame row
-
-    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
-        const int nt = tile / a.P;
-        const int p = a.p_begin + (tile - nt * a.P);
-        const int n0 = nt * NT;
-
-        f32x16 acc[CT];
-#pragma unroll
-        for (int t = 0; t < CT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-        // chunk iterator state (uniform): segment s, chunk cc inside it, A chunk index ach
-        int s = 0, cc = 0, ach = 0;
-        auto skip_invalid = [&]() {
-            while (s < a.nseg && !seg_pos(a.seg[s], p).valid) {
-                ach += (a.seg[s].nchan + KC - 1) / KC;
-                ++s;
-            }
-        };
-        skip_invalid();
-
-        f32x4 v0[4], v1[4];
-        float k0[4], k1[4], k2[4];
-        int cur_mode = 0;
-        auto issue_loads = [&](int ss, int cci) {
-            const trunet_seg& sg = a.seg[ss];
-            const int q = seg_pos(sg, p).q;
-            cur_mode = sg.mode;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int ci = cci * KC + srow + 8 * i;
-                bool ok = ci < sg.nchan;
-                size_t off = ((size_t)ci * sg.L + q) * a.NP + n0 + 4 * sf4;
-                f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                v0[i] = ok ? *(const f32x4*)(sg.src0 + off) : z;
-                if (sg.mode == TRUNET_PRO_BNBWD) v1[i] = ok ? *(const f32x4*)(sg.src1 + off) : z;
-                if (sg.mode != TRUNET_PRO_NONE) {
-                    k0[i] = ok ? sg.c0[ci] : 0.f;
-                    k1[i] = ok ? sg.c1[ci] : 0.f;
-                    if (sg.mode == TRUNET_PRO_BNBWD) k2[i] = ok ? sg.c2[ci] : 0.f;
-                }
-            }
-        };
-        auto write_lds = [&](int buf) {
-            float* Bb = B_lds + buf * (KC * NT);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                f32x4 v = v0[i];
-                if (cur_mode == TRUNET_PRO_BNRELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], k0[i], k1[i]), 0.f);
-                } else if (cur_mode == TRUNET_PRO_BNBWD) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaf(k0[i], v[e], fmaf(k1[i], v1[i][e], k2[i]));
-                }
-                *(f32x4*)(Bb + (srow + 8 * i) * NT + 4 * sf4) = v;
-            }
-        };
-
-        int buf = 0;
-        if (s < a.nseg) {
-            issue_loads(s, cc);
-            write_lds(0);
+    if (has_work) {
+        // weight block in fragment order: [chunk][rs][kg][lane][4], k-pair = 4*kg + j
+        const int totalA = nck_total * RS * (KP * 64);
+        for (int idx = tid; idx < totalA; idx += 256) {
+            const int j = idx & 3;
+            const int ln = (idx >> 2) & 63;
+            const int rest = idx >> 8;
+            const int kg = rest % (KP / 4);
+            const int rest2 = rest / (KP / 4);
+            const int rr = rest2 % RS;
+            const int ch = rest2 / RS;
+            int s = 0, cc = ch;
+            while (cc >= (a.seg[s].nchan + KC - 1) / KC) { cc -= (a.seg[s].nchan + KC - 1) / KC; ++s; }
+            const int kk = 4 * kg + j;
+            const int ci = cc * KC + 2 * kk + (ln >> 5);
+            const int m = mblk * MB + 32 * rr + (ln & 31);
+            float v = 0.f;
+            if (ci < a.seg[s].nchan && m < a.M)
+                v = a.W[(size_t)(m + a.w_m_off) * a.ldw_m + (size_t)ci * a.ldw_c + a.seg[s].woff];
+            A_lds[idx] = v;
         }
-        __syncthreads();
-
-        while (s < a.nseg) {
-            // next chunk (uniform)
-            int s2 = s, cc2 = cc + 1, ach2 = ach;
-            if (cc2 >= (a.seg[s].nchan + KC - 1) / KC) {
-                ach2 += (a.seg[s].nchan + KC - 1) / KC;
-                s2 = s + 1;
-                cc2 = 0;
-                while (s2 < a.nseg && !seg_pos(a.seg[s2], p).valid) {
-                    ach2 += (a.seg[s2].nchan + KC - 1) / KC;
-                    ++s2;
+        int base = 0;
+        for (int s = 0; s < a.nseg; ++s) {
+            const trunet_seg& sg = a.seg[s];
+            for (int ci = tid; ci < sg.nchan; ci += 256) {
+                f32x4 k;
+                if (TWO) {
+                    const bool on = sg.mode == TRUNET_PRO_BNBWD;
+                    k[0] = on ? sg.c0[ci] : 1.f; k[1] = on ? sg.c1[ci] : 0.f; k[2] = on ? sg.c2[ci] : 0.f; k[3] = 0.f;
+                } else {
+                    const bool on = sg.mode == TRUNET_PRO_BNRELU;
+                    k[0] = on ? sg.c0[ci] : 1.f; k[1] = on ? sg.c1[ci] : 0.f; k[2] = on ? 0.f : -3.0e38f; k[3] = 0.f;
                 }
+                C_lds[base + ci] = k;
             }
-            const bool more = s2 < a.nseg;
-            if (more) issue_loads(s2, cc2);
-
-            // ---- MFMAs on the current chunk
-            const float* Ab = A_lds + (size_t)((ach + cc) * RS + rs) * 1024;
-            const float* Bb = B_lds + buf * (KC * NT);
-#pragma unroll
-            for (int kg = 0; kg < 4; ++kg) {
-                f32x4 a4 = *(const f32x4*)(Ab + (kg * 64 + lane) * 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int row = 2 * (4 * kg + j) + h;
-                    bvec b = *(const bvec*)(Bb + row * NT + (32 * RS) * cg + CT * c);
-#pragma unroll
-                    for (int t = 0; t < CT; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], vget<CT>(b, t), acc[t], 0, 0, 0);
-                }
-            }
-            if (more) write_lds(buf ^ 1);
-            __syncthreads();
-            buf ^= 1;
-            s = s2; cc = cc2; ach = ach2;
+            base += sg.nchan;
         }
+        for (int r = tid; r < MB; r += 256) {
+            const int m = mblk * MB + r;
+            const int mg = m + a.m_out_off;
+            const bool ok = m < a.M;
+            E_lds[r] = (ok && (a.epi & TRUNET_EPI_BIAS)) ? a.bias[mg] : 0.f;
+            E_lds[MB + r] = (ok && EPL > 0) ? a.e0[mg] : 0.f;
+            E_lds[2 * MB + r] = (ok && EPL > 0) ? a.e1[mg] : 0.f;
+            E_lds[3 * MB + r] = (ok && EPL > 0 && a.e2) ? a.e2[mg] : 0.f;
+        }
+    }
+    __syncthreads();
 
-        // ---- epilogue
-        const int nb = n0 + (32 * RS) * cg + CT * c;
+    if (has_work) {
+        // ---- LDS-DMA of one chunk.  Wave w, instruction i: row pair g = (LPW/NSRC)*w + i/NSRC of tensor i%NSRC;
+        // 64 lanes x 16 B = rows 2g, 2g+1 (512 B each) contiguous in LDS.  The SAME thread later transforms
+        // exactly the bytes it requested, so the prologue pass needs no barrier of its own.
+        auto issue_dma = [&](const ChunkIt& it, int slot) {
+            const trunet_seg& sg = a.seg[it.s];
+            const int q = seg_pos(sg, it.p).q;
+            float* dst = R_lds + (size_t)slot * CHF;
+            int ci = it.cc * KC + 2 * ((LPW / NSRC) * wave) + h;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ml = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int m = mblk * MB + 32 * rs + ml;
-            if (m < a.M) {
+            for (int i = 0; i < LPW; ++i) {
+                const int g = (LPW / NSRC) * wave + i / NSRC;
+                const int cch = min(ci + 2 * (i / NSRC), sg.nchan - 1);   // rows past the segment: finite filler (A = 0)
+                const float* src = (TWO && (i % NSRC)) ? (sg.src1 ? sg.src1 : sg.src0) : sg.src0;
+                const float* gp = src + ((size_t)cch * sg.L + q) * a.NP + it.n0 + 4 * c;
+                __builtin_amdgcn_global_load_lds(gp, (lds_ptr_t)(dst + (i % NSRC) * (KC * NT) + g * 256), 16, 0, 0);
+            }
+        };
+        // in-place prologue on this thread's own pieces of the chunk in `slot`
+        auto transform = [&](const ChunkIt& it, int slot) {
+            float* dst = R_lds + (size_t)slot * CHF;
+            const int nrow = a.seg[it.s].nchan - it.cc * KC;
+#pragma unroll
+            for (int i = 0; i < LPW / NSRC; ++i) {
+                const int row = 2 * ((LPW / NSRC) * wave + i) + h;
+                float* pz = dst + row * NT + 4 * c;
+                f32x4 v = *(f32x4*)pz;
+                const f32x4 k = C_lds[it.cbase + it.cc * KC + min(row, nrow - 1)];
+                if (TWO) {
+                    const f32x4 z = *(const f32x4*)(pz + KC * NT);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(k[0], v[e], fmaf(k[1], z[e], k[2]));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], k[0], k[1]), k[2]);
+                }
+                *(f32x4*)pz = v;
+            }
+        };
+
+        // ---- pipeline prologue
+        it_enter_tile<KC>(a, cur);
+        ChunkIt ld = cur, ldlast = cur;
+        for (int d = 0; d < NB; ++d) {
+            if (ld.valid) ldlast = ld;
+            issue_dma(ldlast, d);                       // past the end: harmless re-load of the last chunk
+            if (ld.valid) it_next<KC>(a, ld);
+        }
+        ChunkIt tf = cur;                               // chunk whose prologue pass comes next
+        int tslot = 0;
+        wait_vmcnt((NB - 1) * LPW);
+        transform(tf, tslot);
+        it_next<KC>(a, tf);
+        tslot = 1;
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+
+        int slot = 0;
+        while (cur.valid) {                              // ---- tiles
+            f32x16 acc[CT];
+#pragma unroll
+            for (int t = 0; t < CT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            const int tp = cur.p;
+            const int nb = cur.n0 + (32 * RS) * cg + CT * c;
+            bvec zv[16], ov[16];
+            bool last = false;
+            while (!last) {                              // ---- chunks of the tile
+                ChunkIt nxt = cur;
+                last = it_next<KC>(a, nxt);
+                if (EPL > 0 && last) {                   // epilogue operands: issued before the MFMAs
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ml = 32 * rs + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const int m = min(mblk * MB + ml, a.M - 1);
+                        const size_t off = ((size_t)(m + a.m_out_off) * a.out_L + tp + a.out_pos_off) * a.NP + nb;
+                        zv[r] = *(const bvec*)(a.zmask + off);
+                        if (EPL > 1) ov[r] = *(const bvec*)(a.out + off);
+                    }
+                }
+                // prologue pass on the next chunk (its DMA was issued NB-1 chunks ago)
+                if (tf.valid) {
+                    if (EPL > 0 && last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else wait_vmcnt((NB - 2) * LPW);
+                    transform(tf, tslot);
+                    it_next<KC>(a, tf);
+                    tslot = (tslot + 1 == NB) ? 0 : tslot + 1;
+                }
+                // fragments of chunk `cur`, then the MFMAs
+                {
+                    const float* Ab = A_lds + (size_t)((cur.ach + cur.cc) * RS + rs) * (KP * 64);
+                    const float* Bb = R_lds + (size_t)slot * CHF + (32 * RS) * cg + CT * c;
+                    f32x4 af[KP / 4];
+                    bvec bf[KP];
+#pragma unroll
+                    for (int kg = 0; kg < KP / 4; ++kg) af[kg] = *(const f32x4*)(Ab + (kg * 64 + lane) * 4);
+#pragma unroll
+                    for (int kk = 0; kk < KP; ++kk) bf[kk] = *(const bvec*)(Bb + (2 * kk + h) * NT);
+#pragma unroll
+                    for (int kk = 0; kk < KP; ++kk)
+#pragma unroll
+                        for (int t = 0; t < CT; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk >> 2][kk & 3], vget<CT>(bf[kk], t),
+                                                                          acc[t], 0, 0, 0);
+                    // keep the LDS reads LA k-pairs ahead of the MFMAs that consume them (hipcc otherwise sinks
+                    // every ds_read directly in front of its MFMAs and the matrix pipe idles on LDS latency)
+                    constexpr int LA = 1 + 4 / CT;
+                    __builtin_amdgcn_sched_group_barrier(0x100, KP / 4 + LA, 0);
+#pragma unroll
+                    for (int kk = 0; kk < KP - LA; ++kk) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, CT, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, LA * CT, 0);
+                }
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                // slot `slot` is free for everyone now: refill it with chunk (cur + NB)
+                if (ld.valid) ldlast = ld;
+                issue_dma(ldlast, slot);
+                if (ld.valid) it_next<KC>(a, ld);
+                slot = (slot + 1 == NB) ? 0 : slot + 1;
+                cur = nxt;
+            }
+            // ---- epilogue of the tile
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = 32 * rs + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int m = mblk * MB + ml;
                 const int mg = m + a.m_out_off;
-                const size_t off = ((size_t)mg * a.out_L + p + a.out_pos_off) * a.NP + nb;
+                const size_t off = ((size_t)mg * a.out_L + tp + a.out_pos_off) * a.NP + nb;
                 bvec val;
+                const float bv = E_lds[ml];
 #pragma unroll
-                for (int t = 0; t < CT; ++t) vset<CT>(val, t, acc[t][r]);
-                if (a.epi & TRUNET_EPI_BIAS) {
-                    float bv = a.bias[mg];
+                for (int t = 0; t < CT; ++t) vset<CT>(val, t, acc[t][r] + bv);
+                if (EPL > 1) {
 #pragma unroll
-                    for (int t = 0; t < CT; ++t) vset<CT>(val, t, vget<CT>(val, t) + bv);
+                    for (int t = 0; t < CT; ++t) vset<CT>(val, t, vget<CT>(val, t) + vget<CT>(ov[r], t));
                 }
-                if (a.epi & TRUNET_EPI_ACCUM) {
-                    bvec old = *(const bvec*)(a.out + off);
-#pragma unroll
-                    for (int t = 0; t < CT; ++t) vset<CT>(val, t, vget<CT>(val, t) + vget<CT>(old, t));
-                }
-                bvec zv;
                 float e2 = 0.f;
-                if (a.epi & TRUNET_EPI_MASK) {
-                    zv = *(const bvec*)(a.zmask + off);
-                    const float e0 = a.e0[mg], e1 = a.e1[mg];
-                    e2 = a.e2 ? a.e2[mg] : 0.f;
+                if (EPL > 0) {
+                    const float e0 = E_lds[MB + ml], e1 = E_lds[2 * MB + ml];
+                    e2 = E_lds[3 * MB + ml];
 #pragma unroll
                     for (int t = 0; t < CT; ++t)
-                        vset<CT>(val, t, (fmaf(e0, vget<CT>(zv, t), e1) > 0.f) ? vget<CT>(val, t) : 0.f);
+                        vset<CT>(val, t, (fmaf(e0, vget<CT>(zv[r], t), e1) > 0.f) ? vget<CT>(val, t) : 0.f);
                 }
                 if (a.epi & TRUNET_EPI_RELU) {
 #pragma unroll
                     for (int t = 0; t < CT; ++t) vset<CT>(val, t, fmaxf(vget<CT>(val, t), 0.f));
                 }
-                *(bvec*)(a.out + off) = val;
+                if (m < a.M) *(bvec*)(a.out + off) = val;
                 if (a.epi & TRUNET_EPI_STATS) {
 #pragma unroll
                     for (int t = 0; t < CT; ++t) {
-                        float x = (nb + t < a.N) ? vget<CT>(val, t) : 0.f;
+                        const float x = (nb + t < a.N && m < a.M) ? vget<CT>(val, t) : 0.f;
                         st1[r] += x;
-                        if (a.epi & TRUNET_EPI_MASK) st2[r] = fmaf(x, vget<CT>(zv, t) - e2, st2[r]);
+                        if (EPL > 0) st2[r] = fmaf(x, vget<CT>(zv[r], t) - e2, st2[r]);
                         else st2[r] = fmaf(x, x, st2[r]);
                     }
                 }
             }
         }
+        // drain the ring before the workgroup exits
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
     if (a.epi & TRUNET_EPI_STATS) {
@@ -274,18 +397,70 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_kernel(const trunet_gemm_arg
     }
 }
 
-int pick_rs(int M, int nck_total) {
-    int rs = M > 64 ? 4 : (M > 32 ? 2 : 1);
-    while (rs > 1 && (size_t)nck_total * rs * 4096 > 112 * 1024) rs >>= 1;
-    return rs;
+template <int RS, int KC, bool TWO, int EPL>
+int launch_gemm(const trunet_gemm_args* h, int NB, size_t lds, hipStream_t st) {
+    const int mb = 32 * RS;
+    dim3 grid(TRUNET_NUM_CU, (h->M + mb - 1) / mb);
+    auto kern = conv_gemm_kernel<RS, KC, TWO, EPL>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return TRUNET_ELAUNCH;
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, *h, NB);
+    return trunet_launch_status();
+}
+
+template <int RS>
+int launch_gemm_rs(const trunet_gemm_args* h, int kc, bool two, int epl, int NB, size_t lds, hipStream_t st) {
+    if (two && kc == 32) {
+        if (epl == 0) return launch_gemm<RS, 32, true, 0>(h, NB, lds, st);
+        if (epl == 1) return launch_gemm<RS, 32, true, 1>(h, NB, lds, st);
+        return launch_gemm<RS, 32, true, 2>(h, NB, lds, st);
+    }
+    if (two) {
+        if (epl == 0) return launch_gemm<RS, 16, true, 0>(h, NB, lds, st);
+        if (epl == 1) return launch_gemm<RS, 16, true, 1>(h, NB, lds, st);
+        return launch_gemm<RS, 16, true, 2>(h, NB, lds, st);
+    }
+    if (epl == 0) return launch_gemm<RS, 32, false, 0>(h, NB, lds, st);
+    if (epl == 1) return launch_gemm<RS, 32, false, 1>(h, NB, lds, st);
+    return launch_gemm<RS, 32, false, 2>(h, NB, lds, st);
+}
+
+// launch geometry shared by trunet_conv_gemm and (for reporting) the host: row slices, chunk rows, ring slots
+struct GemmPlan { int rs, kc, nb; size_t lds; bool two; int epl; };
+
+int plan_gemm(const trunet_gemm_args* h, GemmPlan* pl) {
+    bool two = false;
+    int nchan_total = 0, kpad32 = 0;
+    for (int s = 0; s < h->nseg; ++s) {
+        two = two || h->seg[s].mode == TRUNET_PRO_BNBWD;
+        nchan_total += h->seg[s].nchan;
+        kpad32 += (h->seg[s].nchan + 31) / 32 * 32;
+    }
+    int rs0 = h->M > 64 ? 4 : (h->M > 32 ? 2 : 1);
+    const size_t budget = 160 * 1024;
+    for (int rs = rs0; rs >= 1; rs >>= 1) {
+        for (int kc = 32; kc >= (two ? 16 : 32); kc >>= 1) {
+            int kpad = 0;
+            for (int s = 0; s < h->nseg; ++s) kpad += (h->seg[s].nchan + kc - 1) / kc * kc;
+            const size_t slot = (size_t)kc * NT * sizeof(float) * (two ? 2 : 1);
+            const size_t fixed = (size_t)kpad * rs * 128 + (size_t)nchan_total * 16 + 4 * 32 * rs * sizeof(float);
+            if (fixed + 3 * slot > budget) continue;
+            int nb = (int)((budget - fixed) / slot);
+            if (nb > 6) nb = 6;
+            pl->rs = rs; pl->kc = kc; pl->nb = nb; pl->lds = fixed + nb * slot; pl->two = two;
+            pl->epl = (h->epi & TRUNET_EPI_MASK) ? ((h->epi & TRUNET_EPI_ACCUM) ? 2 : 1) : 0;
+            return TRUNET_OK;
+        }
+    }
+    (void)kpad32;
+    return TRUNET_ENOTSUP;
 }
 
 }  // namespace
 
 extern "C" int trunet_conv_gemm_nparts(int M) {
-    // upper bound independent of the K extent: 256 workgroups x up to 4 column groups
     (void)M;
-    return TRUNET_NUM_CU * 4;
+    return TRUNET_NUM_CU * 4;   // 256 workgroups x up to 4 column groups
 }
 
 extern "C" int trunet_conv_gemm(const trunet_gemm_args* h, void* stream) {
@@ -293,46 +468,31 @@ extern "C" int trunet_conv_gemm(const trunet_gemm_args* h, void* stream) {
     if (h->NP <= 0 || (h->NP % NT) != 0 || h->N > h->NP || h->P <= 0 || h->M <= 0) return TRUNET_EINVAL;
     if ((h->epi & TRUNET_EPI_STATS) && !h->partials) return TRUNET_EINVAL;
     if ((h->epi & TRUNET_EPI_MASK) && (!h->zmask || !h->e0 || !h->e1)) return TRUNET_EINVAL;
+    if ((h->epi & TRUNET_EPI_ACCUM) && !(h->epi & TRUNET_EPI_MASK)) return TRUNET_ENOTSUP;
     if ((h->epi & TRUNET_EPI_BIAS) && !h->bias) return TRUNET_EINVAL;
-    int nck = 0;
+    bool any_two = false, any_relu = false;
     for (int s = 0; s < h->nseg; ++s) {
         const trunet_seg& sg = h->seg[s];
         if (!sg.src0 || sg.nchan <= 0 || sg.pos_div <= 0) return TRUNET_EINVAL;
         if (sg.mode == TRUNET_PRO_BNBWD && (!sg.src1 || !sg.c0 || !sg.c1 || !sg.c2)) return TRUNET_EINVAL;
         if (sg.mode == TRUNET_PRO_BNRELU && (!sg.c0 || !sg.c1)) return TRUNET_EINVAL;
-        nck += (sg.nchan + KC - 1) / KC;
+        any_two = any_two || sg.mode == TRUNET_PRO_BNBWD;
+        any_relu = any_relu || sg.mode == TRUNET_PRO_BNRELU;
     }
-    const int rs = pick_rs(h->M, nck);
-    const size_t lds = (size_t)nck * rs * 4096 + 2 * KC * NT * sizeof(float);
-    if (lds > 160 * 1024) return TRUNET_ENOTSUP;
-    const int mb = 32 * rs;
-    dim3 grid(TRUNET_NUM_CU, (h->M + mb - 1) / mb);
+    if (any_two && any_relu) return TRUNET_ENOTSUP;   // one prologue family per launch
+    GemmPlan pl;
+    if (plan_gemm(h, &pl) != TRUNET_OK) return TRUNET_ENOTSUP;
     hipStream_t st = (hipStream_t)stream;
     if (h->epi & TRUNET_EPI_STATS) {
         // statistics rows are indexed by (blockIdx.x*CG + cg); rows of unused parts must read as zero
         size_t bytes = (size_t)trunet_conv_gemm_nparts(h->M) * h->M_stat * 2 * sizeof(float);
-        if (h->m_out_off == 0 && h->M == h->M_stat) {
-            if (hipMemsetAsync(h->partials, 0, bytes, st) != hipSuccess) return TRUNET_ELAUNCH;
-        }
+        if (hipMemsetAsync(h->partials, 0, bytes, st) != hipSuccess) return TRUNET_ELAUNCH;
     }
-    switch (rs) {
-        case 4: {
-            hipFuncSetAttribute((const void*)conv_gemm_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(conv_gemm_kernel<4>, grid, dim3(256), lds, st, *h);
-            break;
-        }
-        case 2: {
-            hipFuncSetAttribute((const void*)conv_gemm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(conv_gemm_kernel<2>, grid, dim3(256), lds, st, *h);
-            break;
-        }
-        default: {
-            hipFuncSetAttribute((const void*)conv_gemm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(conv_gemm_kernel<1>, grid, dim3(256), lds, st, *h);
-            break;
-        }
+    switch (pl.rs) {
+        case 4: return launch_gemm_rs<4>(h, pl.kc, pl.two, pl.epl, pl.nb, pl.lds, st);
+        case 2: return launch_gemm_rs<2>(h, pl.kc, pl.two, pl.epl, pl.nb, pl.lds, st);
+        default: return launch_gemm_rs<1>(h, pl.kc, pl.two, pl.epl, pl.nb, pl.lds, st);
     }
-    return trunet_launch_status();
 }
 
 // =====================================================================================

@@ -24,11 +24,12 @@ BN_MOM = 0.1
 # bench.py sets this to a dict to time kernels with HIP events on the launch stream:
 # PROFILE[kernel] = [(start_event, end_event, algorithmic_flops), ...]
 PROFILE = None
+PROFILE_LOG = None
 
 
 class _Timed:
-    def __init__(self, name, flops=0.0):
-        self.name, self.flops = name, flops
+    def __init__(self, name, flops=0.0, tag=""):
+        self.name, self.flops, self.tag = name, flops, tag
 
     def __enter__(self):
         if PROFILE is not None:
@@ -41,6 +42,8 @@ class _Timed:
         if PROFILE is not None:
             self.b.record()
             PROFILE.setdefault(self.name, []).append((self.a, self.b, self.flops))
+            if PROFILE_LOG is not None:
+                PROFILE_LOG.append((self.name, self.tag, self.a, self.b, self.flops))
         return False
 
 
@@ -164,7 +167,10 @@ class TRUNetEngine:
         a.epi = epi
         if PROFILE is not None:
             fl = 2.0 * N * M * sum(s.nchan * _seg_positions(s, p_begin, P) for s in segs)
-            with _Timed("conv_gemm_kernel<%d>" % _gemm_rs(M, segs), fl):
+            tag = "M%d K%s P%d%s%s" % (M, "+".join(str(s.nchan) for s in segs), P,
+                                       " two" if any(s.mode == PRO_BNBWD for s in segs) else "",
+                                       " mask" if zmask is not None else "")
+            with _Timed("conv_gemm_kernel<%d>" % _gemm_rs(M, segs), fl, tag):
                 check(L.lib().trunet_conv_gemm(a, L.stream()), "conv_gemm")
             return nparts
         check(L.lib().trunet_conv_gemm(a, L.stream()), "conv_gemm")
@@ -346,7 +352,7 @@ class TRUNetEngine:
         a.b_stride, a.b_off = bt, b_off
         if PROFILE is not None:
             fl = 2.0 * N * M * sum(s.nchan * _seg_positions(s, 0, P) for s in segs)
-            with _Timed("conv_wgrad_kernel", fl):
+            with _Timed("conv_wgrad_kernel", fl, "M%d K%s P%d" % (M, "+".join(str(s.nchan) for s in segs), P)):
                 check(lib.trunet_conv_wgrad(a, L.stream()), "conv_wgrad")
         else:
             check(lib.trunet_conv_wgrad(a, L.stream()), "conv_wgrad")
