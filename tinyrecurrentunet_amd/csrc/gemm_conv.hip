@@ -397,6 +397,146 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_kernel(const trunet_gemm_arg
     }
 }
 
+
+// ---- M <= 8 outputs: the same implicit GEMM on the vector ALU (the matrix tiles would be 3/4 padding and the
+// layer is a pure HBM stream: decoder.5 pw 128->8, ConvTranspose1d 8->8 and its data gradient).
+// Thread = (position p, 4 frames); weights [channel][8] and prologue coefficients sit in LDS (broadcast reads).
+template <int EPL>
+__global__ __launch_bounds__(256) void conv_smallm_kernel(const trunet_gemm_args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ double red[256];
+    int nchan_total = 0;
+    for (int s = 0; s < a.nseg; ++s) nchan_total += a.seg[s].nchan;
+    f32x4* Wl = (f32x4*)smem;                 // [nchan_total][2]
+    f32x4* Cl = Wl + 2 * nchan_total;         // [nchan_total]
+    const int tid = threadIdx.x;
+    {
+        int base = 0;
+        for (int s = 0; s < a.nseg; ++s) {
+            const trunet_seg& sg = a.seg[s];
+            for (int ci = tid; ci < sg.nchan; ci += 256) {
+                float w[8];
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+                    w[m] = (m < a.M) ? a.W[(size_t)(m + a.w_m_off) * a.ldw_m + (size_t)ci * a.ldw_c + sg.woff] : 0.f;
+                f32x4 w0 = {w[0], w[1], w[2], w[3]}, w1 = {w[4], w[5], w[6], w[7]};
+                Wl[2 * (base + ci)] = w0;
+                Wl[2 * (base + ci) + 1] = w1;
+                const bool on = sg.mode == TRUNET_PRO_BNRELU;
+                f32x4 k = {on ? sg.c0[ci] : 1.f, on ? sg.c1[ci] : 0.f, on ? 0.f : -3.0e38f, 0.f};
+                Cl[base + ci] = k;
+            }
+            base += sg.nchan;
+        }
+    }
+    __syncthreads();
+    const int f4 = tid & 31, py = tid >> 5;
+    const int ntn = a.NP / NT;
+    const int items = a.P * ntn;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) { s1[m] = 0.f; s2[m] = 0.f; }
+    for (int it = blockIdx.x * 8 + py; it < items; it += gridDim.x * 8) {
+        const int nt = it / a.P;
+        const int p = a.p_begin + (it - nt * a.P);
+        const int n = nt * NT + 4 * f4;
+        f32x4 acc[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int cb = 0;
+        for (int s = 0; s < a.nseg; ++s) {
+            const trunet_seg& sg = a.seg[s];
+            const SegPos sp = seg_pos(sg, p);
+            if (sp.valid) {
+                const float* src = sg.src0 + (size_t)sp.q * a.NP + n;
+                const size_t cstr = (size_t)sg.L * a.NP;
+#pragma unroll 4
+                for (int ci = 0; ci < sg.nchan; ++ci) {
+                    f32x4 v = *(const f32x4*)(src + ci * cstr);
+                    const f32x4 k = Cl[cb + ci];
+                    const f32x4 w0 = Wl[2 * (cb + ci)], w1 = Wl[2 * (cb + ci) + 1];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], k[0], k[1]), k[2]);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            acc[m][e] = fmaf(w0[m], v[e], acc[m][e]);
+                            acc[4 + m][e] = fmaf(w1[m], v[e], acc[4 + m][e]);
+                        }
+                }
+            }
+            cb += sg.nchan;
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            if (m < a.M) {
+                const int mg = m + a.m_out_off;
+                const size_t off = ((size_t)mg * a.out_L + p + a.out_pos_off) * a.NP + n;
+                f32x4 val = acc[m];
+                if (a.epi & TRUNET_EPI_BIAS) {
+                    const float bv = a.bias[mg];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) val[e] += bv;
+                }
+                f32x4 zv = {0.f, 0.f, 0.f, 0.f};
+                float e2 = 0.f;
+                if (EPL > 1) {
+                    const f32x4 old = *(const f32x4*)(a.out + off);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) val[e] += old[e];
+                }
+                if (EPL > 0) {
+                    zv = *(const f32x4*)(a.zmask + off);
+                    const float e0 = a.e0[mg], e1 = a.e1[mg];
+                    e2 = a.e2 ? a.e2[mg] : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) val[e] = (fmaf(e0, zv[e], e1) > 0.f) ? val[e] : 0.f;
+                }
+                if (a.epi & TRUNET_EPI_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], 0.f);
+                }
+                *(f32x4*)(a.out + off) = val;
+                if (a.epi & TRUNET_EPI_STATS) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = (n + e < a.N) ? val[e] : 0.f;
+                        s1[m] += x;
+                        s2[m] = (EPL > 0) ? fmaf(x, zv[e] - e2, s2[m]) : fmaf(x, x, s2[m]);
+                    }
+                }
+            }
+        }
+    }
+    if (a.epi & TRUNET_EPI_STATS) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const double r1 = block_sum_f64((double)s1[m], red);
+            const double r2 = block_sum_f64((double)s2[m], red);
+            if (tid == 0 && m < a.M) {
+                float* pp = a.partials + ((size_t)blockIdx.x * a.M_stat + m + a.m_out_off) * 2;
+                pp[0] = (float)r1;
+                pp[1] = (float)r2;
+            }
+        }
+    }
+}
+
+int launch_smallm(const trunet_gemm_args* h, hipStream_t st) {
+    int nchan_total = 0;
+    for (int s = 0; s < h->nseg; ++s) nchan_total += h->seg[s].nchan;
+    const size_t lds = (size_t)nchan_total * 3 * sizeof(f32x4);
+    const int epl = (h->epi & TRUNET_EPI_MASK) ? ((h->epi & TRUNET_EPI_ACCUM) ? 2 : 1) : 0;
+    const int items = h->P * (h->NP / NT);
+    int grid = (items + 7) / 8;
+    if (grid > 1024) grid = 1024;             // = trunet_conv_gemm_nparts: one statistics row per block
+    if (epl == 0) hipLaunchKernelGGL(conv_smallm_kernel<0>, dim3(grid), dim3(256), lds, st, *h);
+    else if (epl == 1) hipLaunchKernelGGL(conv_smallm_kernel<1>, dim3(grid), dim3(256), lds, st, *h);
+    else hipLaunchKernelGGL(conv_smallm_kernel<2>, dim3(grid), dim3(256), lds, st, *h);
+    return trunet_launch_status();
+}
+
 template <int RS, int KC, bool TWO, int EPL>
 int launch_gemm(const trunet_gemm_args* h, int NB, size_t lds, hipStream_t st) {
     const int mb = 32 * RS;
@@ -488,6 +628,7 @@ extern "C" int trunet_conv_gemm(const trunet_gemm_args* h, void* stream) {
         size_t bytes = (size_t)trunet_conv_gemm_nparts(h->M) * h->M_stat * 2 * sizeof(float);
         if (hipMemsetAsync(h->partials, 0, bytes, st) != hipSuccess) return TRUNET_ELAUNCH;
     }
+    if (h->M <= 8 && !any_two) return launch_smallm(h, st);
     switch (pl.rs) {
         case 4: return launch_gemm_rs<4>(h, pl.kc, pl.two, pl.epl, pl.nb, pl.lds, st);
         case 2: return launch_gemm_rs<2>(h, pl.kc, pl.two, pl.epl, pl.nb, pl.lds, st);
@@ -690,12 +831,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const trunet_wgrad_a
     }
 }
 
-__global__ void reduce_partials_kernel(float* out, const float* partials, int nparts, int numel, int accumulate) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= numel) return;
+__global__ __launch_bounds__(256) void reduce_partials_kernel(float* out, const float* __restrict__ partials, int nparts,
+                                                              int numel, int accumulate) {
+    __shared__ double red[4][64];
+    const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + x;
     double s = 0.0;
-    for (int g = 0; g < nparts; ++g) s += (double)partials[(size_t)g * numel + i];
-    out[i] = (accumulate ? out[i] : 0.f) + (float)s;
+    if (i < numel)
+        for (int g = y; g < nparts; g += 4) s += (double)partials[(size_t)g * numel + i];
+    red[y][x] = s;
+    __syncthreads();
+    if (y == 0 && i < numel) {
+        const double t = red[0][x] + red[1][x] + red[2][x] + red[3][x];
+        out[i] = (accumulate ? out[i] : 0.f) + (float)t;
+    }
 }
 
 }  // namespace
@@ -730,7 +879,7 @@ extern "C" int trunet_conv_wgrad(const trunet_wgrad_args* h, void* stream) {
 extern "C" int trunet_reduce_partials(float* out, const float* partials, int nparts, int numel, int accumulate,
                                       void* stream) {
     if (!out || !partials || nparts <= 0 || numel <= 0) return TRUNET_EINVAL;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((numel + 255) / 256), dim3(256), 0, (hipStream_t)stream, out,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((numel + 63) / 64), dim3(256), 0, (hipStream_t)stream, out,
                        partials, nparts, numel, accumulate);
     return trunet_launch_status();
 }
