@@ -639,32 +639,80 @@ extern "C" int trunet_conv_gemm(const trunet_gemm_args* h, void* stream) {
 // =====================================================================================
 // Weight gradient:  dW(m, c, seg) = sum_{p, n<N} dz[m][p][n] * act_seg[c][q_seg(p)][n]
 //
-// Both operands are streamed; the reduction axis (frames) is the MFMA K axis, so operand rows
-// sit in LDS as [row][64 frames + 4 pad] (pad => conflict-free ds_read_b128 across 16 rows).
-// Persistent workgroups over (p, 64-frame chunk); each wave owns up to 5 output tiles of 32x32
-// (dz row tile x act row tile) in accumulators for the whole kernel and finally writes its part of
-// a per-workgroup partial image of W (native weight addressing), summed by trunet_reduce_partials.
-// Two workgroups per CU hide the staging latency (no register prefetch).
+// Both operands are streamed; the reduction axis (frames) is the MFMA K axis.  A tile is one position p x 32
+// frames of every operand row: [dz rows (dy, and z in BN-backward mode)] [rows of up to nvmax valid segments].
+// Tiles arrive by LDS-DMA into a ring of NB slots (rows of 128 B, 16-byte pieces XOR-swizzled through the
+// per-lane SOURCE address so that the row-per-lane fragment reads are bank-conflict free); the thread that
+// requested a piece applies the prologue to it in place (dz = ca*dy + cb*z + cc, BN+ReLU of the activations,
+// zeroing of frames >= N) and accumulates the bias gradient on the way.  Each wave owns up to 5 output tiles
+// of 32x32 in accumulators for the whole kernel and finally writes its part of a per-workgroup partial image
+// of W (native weight addressing), summed by trunet_reduce_partials.
 // =====================================================================================
 namespace {
 
-constexpr int FC = 64;          // frames per chunk
-constexpr int LROW = FC + 4;    // LDS row stride (floats)
-constexpr int WG_ROWS = 256;    // LDS rows
+constexpr int WFC = 32;         // frames per tile
 constexpr int MAXT = 5;         // accumulator tiles per wave
-constexpr int WGRAD_GRID = 2 * TRUNET_NUM_CU;
+constexpr int WGRAD_GRID = TRUNET_NUM_CU;
 
-__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const trunet_wgrad_args a) {
-    __shared__ __attribute__((aligned(16))) float lds[WG_ROWS * LROW];
+__device__ __forceinline__ void wait_vmcnt_any(int n) {
+    switch (n) {
+#define W_(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+        W_(0) W_(1) W_(2) W_(3) W_(4) W_(5) W_(6) W_(7) W_(8) W_(9) W_(10) W_(11) W_(12) W_(13) W_(14) W_(15)
+        W_(16) W_(17) W_(18) W_(19) W_(20) W_(21) W_(22) W_(23) W_(24) W_(25) W_(26) W_(27) W_(28) W_(29) W_(30) W_(31)
+        W_(32) W_(33) W_(34) W_(35) W_(36) W_(37) W_(38) W_(39) W_(40) W_(41) W_(42) W_(43) W_(44) W_(45) W_(46) W_(47)
+        W_(48) W_(49) W_(50) W_(51) W_(52) W_(53) W_(54) W_(55) W_(56) W_(57) W_(58) W_(59) W_(60)
+#undef W_
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+// swizzled float offset of 16-byte piece `pc` (0..7) of row `r` inside a slot
+__device__ __forceinline__ int wg_off(int r, int pc) { return r * WFC + 4 * (pc ^ ((r >> 1) & 7)); }
+
+template <bool TWO>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const trunet_wgrad_args a, const int NB, const int nvmax,
+                                                            const int rows) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
     const int c = lane & 31;
-    const int MA = (a.M + 31) & ~31;        // padded dz rows
+    const int MA = (a.M + 31) & ~31;          // padded dz rows
     const int nrt = MA / 32;
+    const int DZR = TWO ? 2 * MA : MA;        // rows of the dz block (dy [+ z])
+    const int PPW = MA / 32;                  // dz row groups (8 rows x 128 B per DMA instruction) per wave
+    const int SPW = (rows - DZR) / 32;        // staged-segment row groups per wave
+    const int LPW = PPW * (TWO ? 2 : 1) + SPW;   // DMA instructions per wave per tile
+    const int SLOT = rows * WFC;              // floats per slot
 
-    // global tile enumeration: g -> (seg, ctile, rt), rt fastest
+    float* R_lds = smem;
+    f32x4* CA = (f32x4*)(R_lds + (size_t)NB * SLOT);      // [MA] dz coefficients
+    int ntot = 0;
+    for (int s = 0; s < a.nseg; ++s) ntot += a.seg[s].nchan;
+    f32x4* CB = CA + MA;                                     // [sum nchan] activation coefficients
+
+    for (int r = tid; r < MA; r += 256) {
+        const int ch = min(r, a.M - 1) + a.a_m_off;
+        f32x4 k = {1.f, 0.f, 0.f, 0.f};
+        if (TWO) { k[0] = a.ac0[ch]; k[1] = a.ac1[ch]; k[2] = a.ac2[ch]; }
+        if (r >= a.M) { k[0] = 0.f; k[1] = 0.f; k[2] = 0.f; }
+        CA[r] = k;
+    }
+    {
+        int base = 0;
+        for (int s = 0; s < a.nseg; ++s) {
+            const trunet_seg& sg = a.seg[s];
+            for (int ci = tid; ci < sg.nchan; ci += 256) {
+                const bool on = sg.mode == TRUNET_PRO_BNRELU;
+                f32x4 k = {on ? sg.c0[ci] : 1.f, on ? sg.c1[ci] : 0.f, on ? 0.f : -3.0e38f, 0.f};
+                CB[base + ci] = k;
+            }
+            base += sg.nchan;
+        }
+    }
+
+    // global tile enumeration of the OUTPUT: g -> (seg, ctile, rt), rt fastest; wave w owns g = w, w+4, ...
     int ntile_seg[TRUNET_MAX_SEG];
     int G = 0;
 #pragma unroll
@@ -672,133 +720,227 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const trunet_wgrad_a
         ntile_seg[s] = (s < a.nseg) ? ((a.seg[s].nchan + 31) / 32) * nrt : 0;
         G += ntile_seg[s];
     }
-    // per-slot static description (uniform per wave)
     int t_seg[MAXT], t_ct[MAXT], t_rt[MAXT];
 #pragma unroll
     for (int i = 0; i < MAXT; ++i) {
         int g = wave + 4 * i;
         t_seg[i] = -1; t_ct[i] = 0; t_rt[i] = 0;
         if (g < G) {
-            int s = 0;
 #pragma unroll
             for (int ss = 0; ss < TRUNET_MAX_SEG; ++ss) {
                 if (t_seg[i] < 0) {
-                    if (g < ntile_seg[ss]) { t_seg[i] = ss; }
+                    if (g < ntile_seg[ss]) t_seg[i] = ss;
                     else g -= ntile_seg[ss];
                 }
             }
-            (void)s;
             t_ct[i] = g / nrt;
             t_rt[i] = g - t_ct[i] * nrt;
         }
     }
-
     f32x16 acc[MAXT];
 #pragma unroll
     for (int i = 0; i < MAXT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-
-    float bsum[12];
+    float bsum[6];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) bsum[i] = 0.f;
+    for (int i = 0; i < 6; ++i) bsum[i] = 0.f;
 
-    const int srow = tid >> 4;     // 16 rows per pass
-    const int sf4 = tid & 15;      // float4 within the 64-frame row
-    const int nfc = a.NP / FC;
+    const int nfc = a.NP / WFC;
     const int total_tiles = a.P * nfc;
+    const int t_begin = (int)(((long long)blockIdx.x * total_tiles) / gridDim.x);
+    const int t_end = (int)(((long long)(blockIdx.x + 1) * total_tiles) / gridDim.x);
+    __syncthreads();
 
-    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
-        const int fcx = tile / a.P;
-        const int p = a.p_begin + (tile - fcx * a.P);
-        const int n0 = fcx * FC;
-        const int nf = n0 + 4 * sf4;
-
-        // ---- stage dz rows
+    if (t_begin < t_end) {
+        const int pc = lane & 7;
+        // The workgroup's tile range is cut at position changes: everything that depends on p only (staged
+        // segments, per-lane source rows, coefficients) is set up once per run of tiles with the same p.
+        int t0 = t_begin;
+        while (t0 < t_end) {
+            const int pi = t0 / nfc;
+            const int p = a.p_begin + pi;
+            const int t1 = min(t_end, (pi + 1) * nfc);       // tiles [t0, t1) share p; frame chunk = t - pi*nfc
+            // staged segment list: the valid segments in order, the last one repeated up to nvmax entries
+            int sl[TRUNET_MAX_SEG], sq[TRUNET_MAX_SEG], sbase[TRUNET_MAX_SEG];
+            int nvalid = 0;
+            {
+                int lasts = 0, lastq = 0;
 #pragma unroll
-        for (int ps = 0; ps < 12; ++ps) {
-            const int row = srow + 16 * ps;
-            if (row < MA) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (row < a.M) {
-                    const int ch = row + a.a_m_off;
-                    const size_t off = ((size_t)ch * a.a_L + p + a.a_pos_off) * a.NP + nf;
-                    v = *(const f32x4*)(a.a0 + off);
-                    if (a.a_mode == TRUNET_PRO_BNBWD) {
-                        f32x4 z = *(const f32x4*)(a.a1 + off);
-                        const float k0 = a.ac0[ch], k1 = a.ac1[ch], k2 = a.ac2[ch];
+                for (int s = 0; s < TRUNET_MAX_SEG; ++s) { sl[s] = 0; sq[s] = 0; sbase[s] = -1; }
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaf(k0, v[e], fmaf(k1, z[e], k2));
-                    }
+                for (int s = 0; s < TRUNET_MAX_SEG; ++s) {
+                    if (s < a.nseg) {
+                        const SegPos sp = seg_pos(a.seg[s], p);
+                        if (sp.valid && nvalid < nvmax) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (nf + e >= a.N) v[e] = 0.f;
-                        bsum[ps] += v[e];
+                            for (int j = 0; j < TRUNET_MAX_SEG; ++j) if (j == nvalid) { sl[j] = s; sq[j] = sp.q; }
+                            lasts = s; lastq = sp.q; ++nvalid;
+                        }
                     }
                 }
-                *(f32x4*)(lds + row * LROW + 4 * sf4) = v;
+#pragma unroll
+                for (int j = 0; j < TRUNET_MAX_SEG; ++j) if (j >= nvalid && j < nvmax) { sl[j] = lasts; sq[j] = lastq; }
+                int rb = DZR;
+#pragma unroll
+                for (int j = 0; j < TRUNET_MAX_SEG; ++j) {
+                    if (j < nvalid) {
+#pragma unroll
+                        for (int s = 0; s < TRUNET_MAX_SEG; ++s) if (sl[j] == s) sbase[s] = rb;
+                    }
+                    if (j < nvmax) rb += (a.seg[sl[j]].nchan + 31) & ~31;
+                }
             }
-        }
-        // ---- stage activation rows of the valid segments, compactly after the dz rows
-        int seg_base[TRUNET_MAX_SEG];
-        int rows_used = MA;
+            // per-lane source pointers (frame 0 of this lane's row, logical piece folded in) and coefficient rows
+            const float* pd[6];      // dy rows
+            const float* pzr[6];     // z rows (TWO)
+            const float* ps[10];     // staged-segment rows
+            int cidx[10];            // coefficient index of the staged-segment rows
 #pragma unroll
-        for (int s = 0; s < TRUNET_MAX_SEG; ++s) {
-            seg_base[s] = -1;
-            if (s < a.nseg) {
-                const trunet_seg& sg = a.seg[s];
-                const SegPos sp = seg_pos(sg, p);
-                if (sp.valid) {
-                    seg_base[s] = rows_used;
-                    const int npad = (sg.nchan + 31) & ~31;
-                    for (int r0 = 0; r0 < npad; r0 += 16) {
-                        const int ci = r0 + srow;
-                        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                        if (ci < sg.nchan) {
-                            const size_t off = ((size_t)ci * sg.L + sp.q) * a.NP + nf;
-                            v = *(const f32x4*)(sg.src0 + off);
-                            if (sg.mode == TRUNET_PRO_BNRELU) {
-                                const float k0 = sg.c0[ci], k1 = sg.c1[ci];
+            for (int i = 0; i < 6; ++i) {
+                pd[i] = a.a0; pzr[i] = a.a0;
+                if (i < PPW) {
+                    const int r = 8 * (wave * PPW + i) + (lane >> 3);
+                    const int lc = pc ^ ((r >> 1) & 7);
+                    const int m = min(r, a.M - 1) + a.a_m_off;
+                    const size_t off = ((size_t)m * a.a_L + p + a.a_pos_off) * a.NP + 4 * lc;
+                    pd[i] = a.a0 + off;
+                    if (TWO) pzr[i] = a.a1 + off;
+                }
+            }
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], k0, k1), 0.f);
-                            } else if (sg.mode == TRUNET_PRO_BNBWD) {
-                                f32x4 z = *(const f32x4*)(sg.src1 + off);
-                                const float k0 = sg.c0[ci], k1 = sg.c1[ci], k2 = sg.c2[ci];
+            for (int i = 0; i < 10; ++i) {
+                ps[i] = a.a0; cidx[i] = 0;
+                if (i < SPW) {
+                    const int g = wave * SPW + i;
+                    int rb = 0, sidx = sl[0], q = sq[0], ch0 = 0;
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] = fmaf(k0, v[e], fmaf(k1, z[e], k2));
+                    for (int j = 0; j < TRUNET_MAX_SEG; ++j) {
+                        if (j < nvmax) {
+                            const int srp = (a.seg[sl[j]].nchan + 31) & ~31;
+                            if (8 * g >= rb && 8 * g < rb + srp) { sidx = sl[j]; q = sq[j]; ch0 = 8 * g - rb; }
+                            rb += srp;
+                        }
+                    }
+                    const trunet_seg& sg = a.seg[sidx];
+                    const int r = DZR + 8 * g + (lane >> 3);
+                    const int lc = pc ^ ((r >> 1) & 7);
+                    const int ci = min(ch0 + (lane >> 3), sg.nchan - 1);
+                    ps[i] = sg.src0 + ((size_t)ci * sg.L + q) * a.NP + 4 * lc;
+                    int cb = 0;
+                    for (int s = 0; s < sidx; ++s) cb += a.seg[s].nchan;
+                    cidx[i] = cb + ci;
+                }
+            }
+
+            auto issue_dma = [&](int t, int slot) {
+                const int n0 = (t - pi * nfc) * WFC;
+                float* dst = R_lds + (size_t)slot * SLOT;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    if (i < PPW) {
+                        const int g = wave * PPW + i;
+                        __builtin_amdgcn_global_load_lds(pd[i] + n0, (lds_ptr_t)(dst + g * 256), 16, 0, 0);
+                        if (TWO) __builtin_amdgcn_global_load_lds(pzr[i] + n0, (lds_ptr_t)(dst + (MA / 8 + g) * 256), 16, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 10; ++i) {
+                    if (i < SPW) {
+                        const int g = wave * SPW + i;
+                        __builtin_amdgcn_global_load_lds(ps[i] + n0, (lds_ptr_t)(dst + (DZR / 8 + g) * 256), 16, 0, 0);
+                    }
+                }
+            };
+            // prologue pass on this thread's own pieces of tile t
+            auto transform = [&](int t, int slot) {
+                const int n0 = (t - pi * nfc) * WFC;
+                float* dst = R_lds + (size_t)slot * SLOT;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    if (i < PPW) {
+                        const int r = 8 * (wave * PPW + i) + (lane >> 3);
+                        const int lc = pc ^ ((r >> 1) & 7);
+                        float* pz = dst + r * WFC + 4 * pc;
+                        f32x4 v = *(f32x4*)pz;
+                        const f32x4 k = CA[r];
+                        if (TWO) {
+                            const f32x4 z = *(const f32x4*)(pz + MA * WFC);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fmaf(k[0], v[e], fmaf(k[1], z[e], k[2]));
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] *= k[0];
+                        }
+                        float sacc = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (n0 + 4 * lc + e >= a.N) v[e] = 0.f;
+                            sacc += v[e];
+                        }
+                        bsum[i] += sacc;
+                        *(f32x4*)pz = v;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 10; ++i) {
+                    if (i < SPW) {
+                        const f32x4 k = CB[cidx[i]];
+                        float* pz = dst + (DZR + 8 * (wave * SPW + i) + (lane >> 3)) * WFC + 4 * pc;
+                        f32x4 v = *(f32x4*)pz;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], k[0], k[1]), k[2]);
+                        *(f32x4*)pz = v;
+                    }
+                }
+            };
+
+            // ---- pipeline over tiles [t0, t1): NB tiles in flight, first one transformed
+            for (int d = 0; d < NB; ++d) issue_dma(min(t0 + d, t1 - 1), d);
+            wait_vmcnt_any((NB - 1) * LPW);
+            transform(t0, 0);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            int slot = 0;
+            for (int t = t0; t < t1; ++t) {
+                if (t + 1 < t1) {
+                    wait_vmcnt_any((NB - 2) * LPW);
+                    transform(t + 1, (slot + 1 == NB) ? 0 : slot + 1);
+                }
+                const float* S = R_lds + (size_t)slot * SLOT;
+#pragma unroll
+                for (int i = 0; i < MAXT; ++i) {
+                    if (t_seg[i] >= 0) {
+                        int sb = -1;
+#pragma unroll
+                        for (int s = 0; s < TRUNET_MAX_SEG; ++s) if (t_seg[i] == s) sb = sbase[s];
+                        if (sb >= 0) {
+                            const int ra = t_rt[i] * 32 + c;
+                            const int rb = sb + t_ct[i] * 32 + c;
+#pragma unroll
+                            for (int q = 0; q < WFC / 8; ++q) {
+                                const f32x4 av = *(const f32x4*)(S + wg_off(ra, 2 * q + h));
+                                const f32x4 bv = *(const f32x4*)(S + wg_off(rb, 2 * q + h));
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[i], 0, 0, 0);
                             }
                         }
-                        *(f32x4*)(lds + (rows_used + ci) * LROW + 4 * sf4) = v;
-                    }
-                    rows_used += npad;
-                }
-            }
-        }
-        __syncthreads();
-
-        // ---- MFMAs
-#pragma unroll
-        for (int i = 0; i < MAXT; ++i) {
-            if (t_seg[i] >= 0) {
-                int sb = -1;
-#pragma unroll
-                for (int s = 0; s < TRUNET_MAX_SEG; ++s)
-                    if (t_seg[i] == s) sb = seg_base[s];
-                if (sb >= 0) {
-                    const float* Ar = lds + (t_rt[i] * 32 + c) * LROW + 4 * h;
-                    const float* Br = lds + (sb + t_ct[i] * 32 + c) * LROW + 4 * h;
-#pragma unroll
-                    for (int q = 0; q < FC / 8; ++q) {
-                        f32x4 av = *(const f32x4*)(Ar + 8 * q);
-                        f32x4 bv = *(const f32x4*)(Br + 8 * q);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[i], 0, 0, 0);
                     }
                 }
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                issue_dma(min(t + NB, t1 - 1), slot);        // refill the slot just released
+                slot = (slot + 1 == NB) ? 0 : slot + 1;
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();                     // ring is reused by the next run of tiles
+            asm volatile("" ::: "memory");
+            t0 = t1;
         }
-        __syncthreads();
     }
 
     // ---- write this workgroup's partial image
@@ -818,14 +960,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const trunet_wgrad_a
     }
     if (a.b_partials) {
 #pragma unroll
-        for (int ps = 0; ps < 12; ++ps) {
-            float v = bsum[ps];
-            v += __shfl_xor(v, 8);
+        for (int i = 0; i < 6; ++i) {
+            float v = bsum[i];
             v += __shfl_xor(v, 4);
             v += __shfl_xor(v, 2);
             v += __shfl_xor(v, 1);
-            const int row = srow + 16 * ps;
-            if (sf4 == 0 && row < a.M)
+            const int row = 8 * (wave * PPW + i) + (lane >> 3);
+            if ((lane & 7) == 0 && i < PPW && row < a.M)
                 a.b_partials[(size_t)blockIdx.x * a.b_stride + a.b_off + row] = v;
         }
     }
@@ -855,24 +996,44 @@ extern "C" int trunet_conv_wgrad(const trunet_wgrad_args* h, void* stream) {
     if (!h || !h->a0 || !h->w_partials || h->nseg < 1 || h->nseg > TRUNET_MAX_SEG) return TRUNET_EINVAL;
     if (h->NP <= 0 || (h->NP % NT) != 0 || h->N > h->NP || h->P <= 0 || h->M <= 0 || h->M > 192) return TRUNET_EINVAL;
     if (h->a_mode == TRUNET_PRO_BNBWD && (!h->a1 || !h->ac0 || !h->ac1 || !h->ac2)) return TRUNET_EINVAL;
+    const bool two = h->a_mode == TRUNET_PRO_BNBWD;
     const int MA = (h->M + 31) & ~31;
-    int tiles = 0, rows = MA, maxrows = 0;
+    int tiles = 0, ntot = 0, allrows = 0, maxsrp = 0;
     for (int s = 0; s < h->nseg; ++s) {
         const trunet_seg& sg = h->seg[s];
         if (!sg.src0 || sg.nchan <= 0 || sg.pos_div <= 0) return TRUNET_EINVAL;
-        tiles += ((sg.nchan + 31) / 32) * (MA / 32);
-        maxrows += (sg.nchan + 31) & ~31;
+        if (sg.mode == TRUNET_PRO_BNBWD) return TRUNET_ENOTSUP;
+        if (sg.mode == TRUNET_PRO_BNRELU && (!sg.c0 || !sg.c1)) return TRUNET_EINVAL;
+        const int srp = (sg.nchan + 31) & ~31;
+        tiles += (srp / 32) * (MA / 32);
+        allrows += srp;
+        ntot += sg.nchan;
+        if (srp > maxsrp) maxsrp = srp;
     }
-    // rows staged at once: all segments may be valid unless they are parity-exclusive (pos_div > 1);
-    // the host passes transposed-conv taps with pos_div == stride, of which at most ceil(nseg/stride) are valid
+    // segments with pos_div > 1 are the taps of a strided transposed conv: at most ceil(nseg/stride) are valid at
+    // one position (and they have equal channel counts); otherwise every segment may be valid
+    int nvmax = h->nseg, segrows = allrows;
     if (h->nseg > 1 && h->seg[0].pos_div > 1) {
-        int per = (h->seg[0].nchan + 31) & ~31;
-        int d = h->seg[0].pos_div;
-        maxrows = per * ((h->nseg + d - 1) / d);
+        nvmax = (h->nseg + h->seg[0].pos_div - 1) / h->seg[0].pos_div;
+        segrows = nvmax * maxsrp;
     }
-    rows += maxrows;
-    if (tiles > 4 * MAXT || rows > WG_ROWS) return TRUNET_ENOTSUP;
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(WGRAD_GRID), dim3(256), 0, (hipStream_t)stream, *h);
+    const int rows = MA * (two ? 2 : 1) + segrows;
+    if (tiles > 4 * MAXT || rows > 512 || MA > 6 * 32) return TRUNET_ENOTSUP;
+    const size_t slot = (size_t)rows * WFC * sizeof(float);
+    const size_t fixed = (size_t)(MA + ntot) * sizeof(f32x4);
+    int NB = (int)((160 * 1024 - fixed) / slot);
+    if (NB > 4) NB = 4;
+    if (NB < 2) return TRUNET_ENOTSUP;
+    if ((NB - 1) * (rows / 32) > 60) return TRUNET_ENOTSUP;
+    const size_t lds = fixed + NB * slot;
+    hipStream_t st = (hipStream_t)stream;
+    if (two) {
+        if (hipFuncSetAttribute((const void*)conv_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return TRUNET_ELAUNCH;
+        hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3(WGRAD_GRID), dim3(256), lds, st, *h, NB, nvmax, rows);
+    } else {
+        if (hipFuncSetAttribute((const void*)conv_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return TRUNET_ELAUNCH;
+        hipLaunchKernelGGL(conv_wgrad_kernel<false>, dim3(WGRAD_GRID), dim3(256), lds, st, *h, NB, nvmax, rows);
+    }
     return trunet_launch_status();
 }
 
