@@ -211,6 +211,9 @@ int trunet_stft_loss_bwd(const float* x, const float* y, const float* win, const
 /* PhaseAwareMask.forward (phm.py:31-45 + R5) on interleaved complex64: out = sigmoid(beta(angle m - angle e)) |m| */
 int trunet_phm_fwd(const float* mix_ri, const float* est_ri, float* out, int64_t n, float beta, void* stream);
 
+/* calibration: sustained fp32 MFMA rate at the device's operating clock (out: blocks*256 floats) */
+int trunet_debug_mfma_peak(float* out, int blocks, int iters, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -373,3 +373,36 @@ extern "C" int trunet_sumsq(const float* g, int64_t n, float* out, void* stream)
     hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(256), 0, ST, g, n, out);
     return trunet_launch_status();
 }
+
+// ---------------------------------------------------------------- calibration (bench/diagnostics only)
+namespace {
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters, float seed) {
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float a = seed + threadIdx.x * 1e-3f, b = seed * 0.5f + threadIdx.x * 2e-3f;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[t][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+}  // namespace
+
+/* Sustained fp32 MFMA rate of this device at its operating clock: launches `blocks` x 256 threads, each wave
+ * issuing 16*iters v_mfma_f32_32x32x2_f32 on 4 independent accumulators.  flops = blocks*4*16*iters*4096. */
+extern "C" int trunet_debug_mfma_peak(float* out, int blocks, int iters, void* stream) {
+    if (!out || blocks <= 0 || iters <= 0) return TRUNET_EINVAL;
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, ST, out, iters, 1.0f);
+    return trunet_launch_status();
+}

@@ -926,6 +926,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const trunet_wgrad_a
                                 for (int j = 0; j < 4; ++j)
                                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[i], 0, 0, 0);
                             }
+                            // fragment reads one group ahead of the MFMAs that consume them
+                            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
                         }
                     }
                 }
