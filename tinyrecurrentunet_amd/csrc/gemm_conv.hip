@@ -228,25 +228,34 @@ __global__ __launch_bounds__(256, 1) void conv_gemm_kernel(const trunet_gemm_arg
                 __builtin_amdgcn_global_load_lds(gp, (lds_ptr_t)(dst + (i % NSRC) * (KC * NT) + g * 256), 16, 0, 0);
             }
         };
-        // in-place prologue on this thread's own pieces of the chunk in `slot`
+        // in-place prologue on this thread's own pieces of the chunk in `slot` (all reads first, then the math,
+        // then all writes: the compiler must not serialise read-modify-write pairs through LDS aliasing)
         auto transform = [&](const ChunkIt& it, int slot) {
             float* dst = R_lds + (size_t)slot * CHF;
             const int nrow = a.seg[it.s].nchan - it.cc * KC;
+            f32x4 v[LPW / NSRC], z[LPW / NSRC], k[LPW / NSRC];
 #pragma unroll
             for (int i = 0; i < LPW / NSRC; ++i) {
                 const int row = 2 * ((LPW / NSRC) * wave + i) + h;
-                float* pz = dst + row * NT + 4 * c;
-                f32x4 v = *(f32x4*)pz;
-                const f32x4 k = C_lds[it.cbase + it.cc * KC + min(row, nrow - 1)];
-                if (TWO) {
-                    const f32x4 z = *(const f32x4*)(pz + KC * NT);
+                const float* pz = dst + row * NT + 4 * c;
+                v[i] = *(const f32x4*)pz;
+                if (TWO) z[i] = *(const f32x4*)(pz + KC * NT);
+                k[i] = C_lds[it.cbase + it.cc * KC + min(row, nrow - 1)];
+            }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaf(k[0], v[e], fmaf(k[1], z[e], k[2]));
+            for (int i = 0; i < LPW / NSRC; ++i) {
+                if (TWO) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[i][e] = fmaf(k[i][0], v[i][e], fmaf(k[i][1], z[i][e], k[i][2]));
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], k[0], k[1]), k[2]);
+                    for (int e = 0; e < 4; ++e) v[i][e] = fmaxf(fmaf(v[i][e], k[i][0], k[i][1]), k[i][2]);
                 }
-                *(f32x4*)pz = v;
+            }
+#pragma unroll
+            for (int i = 0; i < LPW / NSRC; ++i) {
+                const int row = 2 * ((LPW / NSRC) * wave + i) + h;
+                *(f32x4*)(dst + row * NT + 4 * c) = v[i];
             }
         };
 
