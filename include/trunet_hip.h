@@ -89,6 +89,9 @@ typedef struct {
 /* number of partial rows a trunet_conv_gemm launch writes (so the caller can size `partials`) */
 int trunet_conv_gemm_nparts(int M);
 int trunet_conv_gemm(const trunet_gemm_args* h_args, void* stream);
+/* launch geometry trunet_conv_gemm picks for these arguments (reporting): kernel instance
+ * conv_gemm_kernel<rs, kc, two, epl> (or conv_smallm_kernel<epl> when M <= 8 and !two), ring of nb LDS slots */
+int trunet_conv_gemm_plan(const trunet_gemm_args* h_args, int* rs, int* kc, int* nb, int* two, int* epl);
 
 /* Weight gradient of the same implicit GEMM (autograd of network.py:28,50,64,67,83,86,106,109,48):
  *   dW[(m+w_m_off)*ldw_m + c*ldw_c + woff_seg] = sum_{p,n<N} dz[m][p][n] * pro_seg(src_seg[c][q_seg(p)][n])

@@ -607,6 +607,14 @@ int plan_gemm(const trunet_gemm_args* h, GemmPlan* pl) {
 
 }  // namespace
 
+extern "C" int trunet_conv_gemm_plan(const trunet_gemm_args* h, int* rs, int* kc, int* nb, int* two, int* epl) {
+    if (!h || !rs || !kc || !nb || !two || !epl) return TRUNET_EINVAL;
+    GemmPlan pl;
+    if (plan_gemm(h, &pl) != TRUNET_OK) return TRUNET_ENOTSUP;
+    *rs = pl.rs; *kc = pl.kc; *nb = pl.nb; *two = pl.two ? 1 : 0; *epl = pl.epl;
+    return TRUNET_OK;
+}
+
 extern "C" int trunet_conv_gemm_nparts(int M) {
     (void)M;
     return TRUNET_NUM_CU * 4;   // 256 workgroups x up to 4 column groups

@@ -56,6 +56,18 @@ def _gemm_rs(M, segs):
     return rs
 
 
+def _gemm_kernel_name(a):
+    """Exact symbol (template arguments included) of the kernel trunet_conv_gemm launches for `a`, so that
+    bench.py's per-kernel numbers can be matched against rocprofv3's kernel names."""
+    import ctypes as C
+    v = [C.c_int() for _ in range(5)]
+    check(L.lib().trunet_conv_gemm_plan(a, *[C.byref(x) for x in v]), "conv_gemm_plan")
+    rs, kc, nb, two, epl = [x.value for x in v]
+    if a.M <= 8 and not two:
+        return "conv_smallm_kernel<%d>" % epl
+    return "conv_gemm_kernel<%d, %d, %s, %d>" % (rs, kc, "true" if two else "false", epl)
+
+
 def _seg_positions(s, p0, P):
     """number of output positions p in [p0, p0+P) for which segment s is valid"""
     n = 0
@@ -170,7 +182,7 @@ class TRUNetEngine:
             tag = "M%d K%s P%d%s%s" % (M, "+".join(str(s.nchan) for s in segs), P,
                                        " two" if any(s.mode == PRO_BNBWD for s in segs) else "",
                                        " mask" if zmask is not None else "")
-            with _Timed("conv_gemm_kernel<%d>" % _gemm_rs(M, segs), fl, tag):
+            with _Timed(_gemm_kernel_name(a), fl, tag):
                 check(L.lib().trunet_conv_gemm(a, L.stream()), "conv_gemm")
             return nparts
         check(L.lib().trunet_conv_gemm(a, L.stream()), "conv_gemm")
@@ -352,7 +364,8 @@ class TRUNetEngine:
         a.b_stride, a.b_off = bt, b_off
         if PROFILE is not None:
             fl = 2.0 * N * M * sum(s.nchan * _seg_positions(s, 0, P) for s in segs)
-            with _Timed("conv_wgrad_kernel", fl, "M%d K%s P%d" % (M, "+".join(str(s.nchan) for s in segs), P)):
+            with _Timed("conv_wgrad_kernel<%s>" % ("true" if dz_bn is not None else "false"), fl,
+                        "M%d K%s P%d" % (M, "+".join(str(s.nchan) for s in segs), P)):
                 check(lib.trunet_conv_wgrad(a, L.stream()), "conv_wgrad")
         else:
             check(lib.trunet_conv_wgrad(a, L.stream()), "conv_wgrad")
