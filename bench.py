@@ -86,6 +86,33 @@ def cpu_baseline(B=4, L=64000, steps=3):
                 B, B * T, len(times) - 1, torch.__version__)}
 
 
+def streaming(args, dev):
+    """rt.py:20-27,76-84 protocol on the GPU: eval-mode forward of a fresh randn (streams, 4, 257) batch under
+    no_grad, one STFT frame (8 ms of 16 kHz audio) per stream per step; frames are independent in the reference
+    forward (no TGRU, R4), so `streams` concurrent streams are one batch of `streams` frames."""
+    from tinyrecurrentunet_amd import network as hn
+    streams = 1024
+    torch.manual_seed(0)
+    net = hn.TRUNet(input_size=4).to(dev).eval()
+    x = torch.randn(streams, 4, 257, device=dev)
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            net(x)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(args.steps):
+            x = torch.randn(streams, 4, 257, device=dev)
+            y = net(x)
+        torch.cuda.synchronize()
+    dt = (time.time() - t0) / args.steps
+    out = {"metric": "streaming forward real-time factor (1024 streams x 1 frame)", "value": round(streams * 0.008 / dt, 1),
+           "unit": "x real time", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+           "frames_per_s": round(streams / dt, 1),
+           "config": {"workload": "config/tiny.json TRU-Net eval forward, randn(1024,4,257) per step (rt.py protocol)"}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,6 +123,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stft-loss", action="store_true", help="ablation (BASELINE.json configs[4])")
     ap.add_argument("--no-pcen", action="store_true", help="ablation (BASELINE.json configs[4])")
+    ap.add_argument("--streaming", action="store_true",
+                    help="BASELINE.json configs[3]: 1-frame causal forward of 1024 concurrent streams (rt.py protocol)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,6 +139,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     from tinyrecurrentunet_amd import distributed as tdist, engine, network as hn, optim, stft_loss as sl, util
+    if args.streaming:
+        return streaming(args, dev)
     cin = 3 if args.no_pcen else 4
     torch.manual_seed(0)                      # train.py:12-14
     net = hn.TRUNet(input_size=cin).to(dev).train()

@@ -143,6 +143,9 @@ int trunet_bn_finalize_bwd(const float* partials, int nparts, int C, double coun
 /* (N,C,L) <-> frames-last [C][L][NP] (zero-fills frames >= N) */
 int trunet_to_frames_last(const float* x_ncl, float* y_clnp, int N, int C, int L, int NP, void* stream);
 int trunet_from_frames_last(const float* x_clnp, float* y_ncl, int N, int C, int L, int NP, void* stream);
+/* same, applying y = max(scale[c]*x + shift[c], relu ? 0 : -inf) (BatchNorm1d+ReLU of a block output, network.py:31-32) */
+int trunet_from_frames_last_affine(const float* x_clnp, float* y_ncl, int N, int C, int L, int NP, const float* scale,
+                                   const float* shift, int relu, void* stream);
 
 /* StandardConv1d forward (network.py:9-21): Conv1d(Cin->Cout,k,s,padding=s/2)+ReLU, frames-last. */
 int trunet_conv_first_fwd(const float* x, const float* w, const float* b, float* y, int Cin, int Cout,

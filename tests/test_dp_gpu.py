@@ -1,0 +1,62 @@
+"""GPU: the data-parallel step (distributed.apply_gradient_allreduce on the HIP TRUNet) with 2 ranks sharing the
+single GPU of the test box over gloo (RCCL needs one GPU per rank; the collective semantics are the same)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from oracle import network_ref as nr, weights as W
+    from tinyrecurrentunet_amd import distributed as td, network as hn
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    # rank-dependent initial weights: the start-up broadcast must make them rank 0's
+    sd = W.fill_state_dict(nr.TRUNet(input_size=4), seed=10 + rank).state_dict()
+    net = hn.TRUNet(input_size=4)
+    net.load_state_dict(sd)
+    net.cuda().train()
+    td.apply_gradient_allreduce(net)
+    xs = [torch.tensor(np.random.default_rng(50 + r).standard_normal((40, 4, 257)) * 0.5, dtype=torch.float32).cuda()
+          for r in range(world)]
+    cot = torch.tensor(np.random.default_rng(60).standard_normal((40, 8, 257)), dtype=torch.float32).cuda()
+    y = net(xs[rank])
+    (y * cot).sum().backward()
+    torch.cuda.synchronize()
+    got = torch.cat([p.grad.reshape(-1) for n, p in net.named_parameters() if p.grad is not None]).cpu()
+    tgru_none = all(p.grad is None for n, p in net.named_parameters() if n.startswith("TGRU"))
+    # expected: mean over ranks of the local gradients from rank 0's weights (BatchNorm statistics stay per rank)
+    exp = 0
+    for r in range(world):
+        ref = hn.TRUNet(input_size=4)
+        ref.load_state_dict(W.fill_state_dict(nr.TRUNet(input_size=4), seed=10).state_dict())
+        ref.cuda().train()
+        yy = ref(xs[r])
+        (yy * cot).sum().backward()
+        exp = exp + torch.cat([p.grad.reshape(-1) for n, p in ref.named_parameters() if p.grad is not None]).cpu()
+    exp = exp / world
+    q.put((rank, float((got - exp).norm() / exp.norm()), got.numel(), tgru_none))
+    dist.destroy_process_group()
+
+
+def test_two_rank_dp_step_matches_mean_of_local_gradients():
+    world, port = 2, 29500 + (os.getpid() % 1000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = [q.get(timeout=300) for _ in range(world)]
+    [p.join(60) for p in ps]
+    for rank, err, n, tgru_none in res:
+        assert n == 298592 and tgru_none
+        assert err < 1e-5, (rank, err)

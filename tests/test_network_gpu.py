@@ -119,3 +119,37 @@ def test_cpu_tensor_fails_loudly():
     from tinyrecurrentunet_amd import network as hn, _lib
     with pytest.raises(_lib.TrunetHipError):
         hn.TRUNet(3)(torch.zeros(2, 3, 257))
+
+
+BLOCKS = {
+    "std": ("StandardConv1d", (4, 64, 5, 2)),
+    "dsc_k3s1": ("DepthwiseSeparableConv1d", (64, 128, 3, 1)),
+    "dsc_k5s2": ("DepthwiseSeparableConv1d", (128, 128, 5, 2)),
+    "dsc_k3s2": ("DepthwiseSeparableConv1d", (128, 128, 3, 2)),
+    "gru_bi": ("GRUBlock", (128, 64, 64, True)),
+    "first_tr": ("FirstTrCNN", (64, 64, 3, 2)),
+    "tr_k5s2": ("TrCNN", (192, 64, 5, 2)),
+    "tr_k3s1": ("TrCNN", (192, 64, 3, 1)),
+    "last_tr": ("LastTrCNN", (128, 8, 5, 2)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(BLOCKS))
+def test_block_forward_matches_reference_golden(golden, name):
+    """Stand-alone block classes (network.py:9-120) vs outputs of the reference's own classes."""
+    from oracle import weights as W
+    from tinyrecurrentunet_amd import network as hn
+    g = golden("block_" + name)
+    cls, args = BLOCKS[name]
+    mod = getattr(hn, cls)(*args)
+    W.fill_state_dict(mod, seed=11)
+    assert abs(W.checksum(mod) - float(g["wsum"])) < 1e-6 * float(g["wsum"])
+    mod.cuda()
+    ins = [torch.tensor(g["x%d" % i]).cuda() for i in range(2) if "x%d" % i in g]
+    mod.eval()
+    assert _rel(mod(*ins), torch.tensor(g["y_eval"])) < 1e-4
+    mod.train()
+    assert _rel(mod(*ins), torch.tensor(g["y_train"])) < 1e-4
+    for bn_, b in mod.named_buffers():
+        if b.is_floating_point():
+            assert _rel(b, torch.tensor(g["buf:" + bn_])) < 1e-4, bn_

@@ -77,6 +77,7 @@ def _declare(L):
         "trunet_bn_finalize_bwd": [p, i, i, d, p, p, p, p, p, p, p, p, p],
         "trunet_to_frames_last": [p, p, i, i, i, i, p],
         "trunet_from_frames_last": [p, p, i, i, i, i, p],
+        "trunet_from_frames_last_affine": [p, p, i, i, i, i, p, p, i, p],
         "trunet_conv_first_fwd": [p, p, p, p, i, i, i, i, i, i, i, p],
         "trunet_dwconv_nparts": [i],
         "trunet_dwconv_bwd_nparts": [i],

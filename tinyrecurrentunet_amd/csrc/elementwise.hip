@@ -37,6 +37,30 @@ __global__ void from_frames_last_kernel(const float* __restrict__ y, float* __re
     }
 }
 
+// Y[R][NP] -> X[N][R] with the consumer-side BatchNorm+ReLU applied on the way out (block outputs of the
+// reference API are post-activation): x = max(scale[c]*y + shift[c], lo), c = r / L
+__global__ void from_frames_last_affine_kernel(const float* __restrict__ y, float* __restrict__ x, int N, int R, int NP,
+                                               int L, const float* __restrict__ scale, const float* __restrict__ shift,
+                                               float lo) {
+    __shared__ float t[32][33];
+    const int n0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    for (int i = ty; i < 32; i += 8) {
+        int r = r0 + i, n = n0 + tx;
+        float v = 0.f;
+        if (r < R && n < NP) {
+            const int c = r / L;
+            v = fmaxf(fmaf(y[(size_t)r * NP + n], scale[c], shift[c]), lo);
+        }
+        t[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        int n = n0 + i, r = r0 + tx;
+        if (n < N && r < R) x[(size_t)n * R + r] = t[tx][i];
+    }
+}
+
 // ---------------------------------------------------------------- first conv (+ReLU)
 // y[co][lo][n] = relu(b[co] + sum_{ci,k} w[co][ci][k] * x[ci][lo*S + k - S/2][n])
 template <int CIN, int K>
@@ -290,6 +314,15 @@ extern "C" int trunet_from_frames_last(const float* x, float* y, int N, int C, i
     if (!x || !y || N <= 0 || NP < N) return TRUNET_EINVAL;
     int R = C * L;
     hipLaunchKernelGGL(from_frames_last_kernel, dim3((NP + 31) / 32, (R + 31) / 32), dim3(32, 8), 0, ST, x, y, N, R, NP);
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_from_frames_last_affine(const float* x, float* y, int N, int C, int L, int NP, const float* scale,
+                                              const float* shift, int relu, void* stream) {
+    if (!x || !y || !scale || !shift || N <= 0 || NP < N) return TRUNET_EINVAL;
+    int R = C * L;
+    hipLaunchKernelGGL(from_frames_last_affine_kernel, dim3((NP + 31) / 32, (R + 31) / 32), dim3(32, 8), 0, ST, x, y, N, R,
+                       NP, L, scale, shift, relu ? 0.f : -3.0e38f);
     return trunet_launch_status();
 }
 

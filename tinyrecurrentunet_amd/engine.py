@@ -267,6 +267,92 @@ class TRUNetEngine:
                   "bn_eval_affine")
         return Act(out, C, Lo, st)
 
+    # ------------------------------------------------------------------ stand-alone blocks (forward only)
+    def _load(self, w, name, x):
+        x = x.contiguous()
+        N, C, Ln = x.shape
+        NP = ceil_to(N, 128)
+        t = w.get("in:" + name, (C, Ln, NP))
+        check(L.lib().trunet_to_frames_last(ptr(x), ptr(t), N, C, Ln, NP, L.stream()), "to_frames_last")
+        return Act(t, C, Ln), N, NP
+
+    def _store(self, act, N, NP, dev):
+        out = torch.empty((N, act.C, act.L), device=dev, dtype=torch.float32)
+        if act.bn is None:
+            check(L.lib().trunet_from_frames_last(ptr(act.t), ptr(out), N, act.C, act.L, NP, L.stream()), "from_frames_last")
+        else:
+            check(L.lib().trunet_from_frames_last_affine(ptr(act.t), ptr(out), N, act.C, act.L, NP, ptr(act.bn.scale),
+                                                         ptr(act.bn.shift), 1, L.stream()), "from_frames_last_affine")
+        return out
+
+    def block_forward(self, kind, seq, xs, training):
+        """Forward of one reference block class (network.py:9-120) on (N, C, L) tensors; returns the block's
+        post-activation output like the reference.  Forward only: training goes through ``TRUNet``."""
+        dev = xs[0].device
+        N = xs[0].shape[0]
+        NP = ceil_to(N, 128)
+        w = self.ws(NP, dev)
+        lib = L.lib()
+        if kind == "std":
+            a, N, NP = self._load(w, "b0", xs[0])
+            conv = seq[0]
+            k, s, pad = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+            if k != 5 or a.C not in (3, 4) or pad != s // 2:
+                raise L.TrunetHipError("StandardConv1d kernel is built for C_in 3/4, k=5 (network.py:134)")
+            Lo = (a.L + 2 * pad - k) // s + 1
+            out = w.get("z:blk", (conv.out_channels, Lo, NP))
+            check(lib.trunet_conv_first_fwd(ptr(a.t), ptr(conv.weight.data), ptr(conv.bias.data), ptr(out), a.C,
+                                            conv.out_channels, k, s, a.L, Lo, NP, L.stream()), "conv_first_fwd")
+            return self._store(Act(out, conv.out_channels, Lo), N, NP, dev)
+        if kind == "dsc":
+            a, N, NP = self._load(w, "b0", xs[0])
+            cur = self._pw(w, "blk.pw", [a], seq[0], seq[1], N, NP, training)
+            cur = self._dw(w, "blk", cur, seq[3], seq[4], N, NP, training)
+            return self._store(cur, N, NP, dev)
+        if kind in ("first_tr", "tr", "last_tr"):
+            a, N, NP = self._load(w, "b0", xs[0])
+            srcs, left = [a], 0
+            if kind != "first_tr":
+                b, _, _ = self._load(w, "b1", xs[1])
+                left = (b.L - a.L) // 2
+                srcs = [a, b]
+            cur = self._pw(w, "blk.pw", srcs, seq[0], seq[1], N, NP, training, x1_left=left)
+            cur = self._convT(w, "blk", cur, seq[3], seq[4] if kind != "last_tr" else None, N, NP, training)
+            return self._store(cur, N, NP, dev)
+        raise ValueError(kind)
+
+    def gru_block_forward(self, blk, x, training):
+        """GRUBlock.forward (network.py:54-58): x (N, L, C_in) -> (N, C_out, L)."""
+        gru = blk.GRU
+        if not gru.bidirectional or gru.hidden_size != 64:
+            raise L.TrunetHipError("the HIP GRU kernel is built for the bidirectional H=64 FGRU (network.py:149); "
+                                   "the unidirectional TGRU (network.py:150) is never executed (R4)")
+        dev = x.device
+        a, N, NP = self._load(self.ws(ceil_to(x.shape[0], 128), dev), "b0", x.transpose(1, 2))
+        w = self.ws(NP, dev)
+        hout = self._gru(w, a, gru, N, NP, training)
+        cur = self._pw(w, "blk.fgru", [hout], blk.conv[0], blk.conv[1], N, NP, training)
+        return self._store(cur, N, NP, dev)
+
+    def _gru(self, w, cur, gru, N, NP, training):
+        """input projection (both directions, M = 6H) + recurrence; returns Act(hout [2H][L][NP])"""
+        lib = L.lib()
+        Hh = gru.hidden_size
+        wih = w.get("wih", (6 * Hh, gru.input_size))
+        bih = w.get("bih", (6 * Hh,))
+        torch.cat((gru.weight_ih_l0.data, gru.weight_ih_l0_reverse.data), 0, out=wih)
+        torch.cat((gru.bias_ih_l0.data, gru.bias_ih_l0_reverse.data), 0, out=bih)
+        Lg = cur.L
+        gi = w.get("gi", (6 * Hh, Lg, NP))
+        self._gemm(w, N=N, NP=NP, P=Lg, M=6 * Hh, out=gi, out_L=Lg, W=wih, ldw_m=gru.input_size, ldw_c=1,
+                   segs=[cur.seg()], bias=bih)
+        hout = w.get("hout", (2 * Hh, Lg, NP))
+        gates = w.get("gates", (2, 4, Hh, Lg, NP)) if training else None
+        check(lib.trunet_gru_fwd(ptr(gi), ptr(gru.weight_hh_l0.data), ptr(gru.bias_hh_l0.data),
+                                 ptr(gru.weight_hh_l0_reverse.data), ptr(gru.bias_hh_l0_reverse.data), ptr(hout),
+                                 ptr(gates), Hh, Lg, NP, L.stream()), "gru_fwd")
+        return Act(hout, 2 * Hh, Lg)
+
     # ------------------------------------------------------------------ forward
     def forward(self, x, training):
         net = self.net
@@ -295,21 +381,7 @@ class TRUNetEngine:
 
         # FGRU: input projection (both directions, M = 384), recurrence, pw conv + BN
         gru = net.FGRU.GRU
-        Hh = gru.hidden_size
-        wih = w.get("wih", (6 * Hh, gru.input_size))
-        bih = w.get("bih", (6 * Hh,))
-        torch.cat((gru.weight_ih_l0.data, gru.weight_ih_l0_reverse.data), 0, out=wih)
-        torch.cat((gru.bias_ih_l0.data, gru.bias_ih_l0_reverse.data), 0, out=bih)
-        Lg = cur.L
-        gi = w.get("gi", (6 * Hh, Lg, NP))
-        self._gemm(w, N=N, NP=NP, P=Lg, M=6 * Hh, out=gi, out_L=Lg, W=wih, ldw_m=gru.input_size, ldw_c=1,
-                   segs=[cur.seg()], bias=bih)
-        hout = w.get("hout", (2 * Hh, Lg, NP))
-        gates = w.get("gates", (2, 4, Hh, Lg, NP)) if training else None
-        check(lib.trunet_gru_fwd(ptr(gi), ptr(gru.weight_hh_l0.data), ptr(gru.bias_hh_l0.data),
-                                 ptr(gru.weight_hh_l0_reverse.data), ptr(gru.bias_hh_l0_reverse.data), ptr(hout),
-                                 ptr(gates), Hh, Lg, NP, st), "gru_fwd")
-        acts["hout"] = Act(hout, 2 * Hh, Lg)
+        acts["hout"] = self._gru(w, cur, gru, N, NP, training)
         cur = acts["fgru"] = self._pw(w, "fgru", [acts["hout"]], net.FGRU.conv[0], net.FGRU.conv[1], N, NP, training)
 
         seq = net.decoder[0].FirstTrCNN

@@ -23,8 +23,28 @@ def _pw_bn_relu(cin, cout):
     return [nn.Conv1d(cin, cout, kernel_size=1), nn.BatchNorm1d(cout), nn.ReLU(inplace=True)]
 
 
-class StandardConv1d(nn.Module):
+class _Block(nn.Module):
+    """Stand-alone use of a block class (the reference's own forward signatures).  Forward only: gradients are
+    produced by the fused schedule behind ``TRUNet``."""
+    _kind = None
+    _seq = None
+
+    def _run(self, *xs):
+        for x in xs:
+            _need_gpu(x)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and \
+                any(x.requires_grad for x in xs):
+            raise _lib.TrunetHipError("stand-alone blocks are forward-only; train through TRUNet")
+        if getattr(self, "_engine", None) is None:
+            object.__setattr__(self, "_engine", TRUNetEngine(self))
+        with torch.no_grad():
+            return self._engine.block_forward(self._kind, getattr(self, self._seq), [x.float() for x in xs],
+                                              self.training)
+
+
+class StandardConv1d(_Block):
     """network.py:9-21."""
+    _kind, _seq = "std", "StandardConv1d"
 
     def __init__(self, in_channels, out_channels, kernel_size, stride):
         super().__init__()
@@ -32,9 +52,16 @@ class StandardConv1d(nn.Module):
             nn.Conv1d(in_channels, out_channels, kernel_size, stride=stride, padding=stride // 2),
             nn.ReLU(inplace=True))
 
+    def forward(self, x):
+        return self._run(x)
 
-class DepthwiseSeparableConv1d(nn.Module):
+
+class DepthwiseSeparableConv1d(_Block):
     """network.py:24-43."""
+    _kind, _seq = "dsc", "DepthwiseSeparableConv1d"
+
+    def forward(self, x):
+        return self._run(x)
 
     def __init__(self, in_channels, out_channels, kernel_size, stride):
         super().__init__()
@@ -54,6 +81,13 @@ class GRUBlock(nn.Module):
         width = hidden_size * (2 if bidirectional else 1)
         self.conv = nn.Sequential(*_pw_bn_relu(width, out_channels))
 
+    def forward(self, x):
+        _need_gpu(x)
+        if getattr(self, "_engine", None) is None:
+            object.__setattr__(self, "_engine", TRUNetEngine(self))
+        with torch.no_grad():
+            return self._engine.gru_block_forward(self, x.float(), self.training)
+
 
 def _trcnn_body(in_channels, out_channels, kernel_size, stride, tail=True):
     layers = _pw_bn_relu(in_channels, out_channels)
@@ -63,24 +97,36 @@ def _trcnn_body(in_channels, out_channels, kernel_size, stride, tail=True):
     return nn.Sequential(*layers)
 
 
-class FirstTrCNN(nn.Module):
+class FirstTrCNN(_Block):
     """network.py:60-76."""
+    _kind, _seq = "first_tr", "FirstTrCNN"
+
+    def forward(self, x):
+        return self._run(x)
 
     def __init__(self, in_channels, out_channels, kernel_size, stride):
         super().__init__()
         self.FirstTrCNN = _trcnn_body(in_channels, out_channels, kernel_size, stride)
 
 
-class TrCNN(nn.Module):
+class TrCNN(_Block):
     """network.py:79-100."""
+    _kind, _seq = "tr", "TrCNN"
+
+    def forward(self, x1, x2):
+        return self._run(x1, x2)
 
     def __init__(self, in_channels, out_channels, kernel_size, stride):
         super().__init__()
         self.TrCNN = _trcnn_body(in_channels, out_channels, kernel_size, stride)
 
 
-class LastTrCNN(nn.Module):
+class LastTrCNN(_Block):
     """network.py:102-120."""
+    _kind, _seq = "last_tr", "LastTrCNN"
+
+    def forward(self, x1, x2):
+        return self._run(x1, x2)
 
     def __init__(self, in_channels, out_channels, kernel_size, stride):
         super().__init__()
@@ -134,7 +180,7 @@ class TRUNet(nn.Module):
             LastTrCNN(128, 8, 5, 2)])
         self.FGRU = GRUBlock(128, 64, 64, bidirectional=True)
         self.TGRU = GRUBlock(64, 128, 64, bidirectional=False)
-        self._engine = None
+        object.__setattr__(self, "_engine", None)
 
     def _active_params(self):
         return [p for n, p in self.named_parameters() if not n.startswith("TGRU.")]
@@ -142,7 +188,7 @@ class TRUNet(nn.Module):
     def forward(self, x):
         _need_gpu(x)
         if self._engine is None:
-            self._engine = TRUNetEngine(self)
+            object.__setattr__(self, "_engine", TRUNetEngine(self))
         params = self._active_params()
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             return _TRUNetFn.apply(x, self._engine, self.training, *params)
