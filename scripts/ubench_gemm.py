@@ -12,7 +12,7 @@ def run(N, Ln, K, M, mode, reps=5):
     out = torch.empty(M, Ln, NP, device=dev)
     W = torch.randn(M, K, device=dev) * 0.05
     b = torch.zeros(M, device=dev); s = torch.ones(K, device=dev); t = torch.zeros(K, device=dev)
-    part = torch.empty(1024 * M * 2, device=dev)
+    part = torch.empty(2048 * M * 2, device=dev)
     a = GemmArgs()
     a.NP, a.N, a.P, a.p_begin = NP, N, Ln, 0
     a.M, a.m_out_off, a.out_L, a.out_pos_off = M, 0, Ln, 0

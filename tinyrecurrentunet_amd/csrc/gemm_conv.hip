@@ -119,7 +119,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 //   issued the DMA (one chunk ahead of the MFMAs)  ->  fragment reads + MFMAs.  One raw s_barrier per chunk;
 //   DMA completion is tracked with counted s_waitcnt vmcnt, so NB-1 chunks (16 KiB each) stay in flight.
 template <int RS, int KC, bool TWO, int EPL>
-__global__ __launch_bounds__(256, 1) void conv_gemm_kernel(const trunet_gemm_args a, const int NB) {
+__global__ __launch_bounds__(256, (EPL == 0) ? 2 : 1) void conv_gemm_kernel(const trunet_gemm_args a, const int NB) {
     constexpr int CT = RS;            // column tiles (of 32 frames) per wave
     constexpr int CG = 4 / RS;        // column groups
     constexpr int MB = 32 * RS;       // rows per M block
@@ -549,7 +549,7 @@ int launch_smallm(const trunet_gemm_args* h, hipStream_t st) {
 template <int RS, int KC, bool TWO, int EPL>
 int launch_gemm(const trunet_gemm_args* h, int NB, size_t lds, hipStream_t st) {
     const int mb = 32 * RS;
-    dim3 grid(TRUNET_NUM_CU, (h->M + mb - 1) / mb);
+    dim3 grid((EPL == 0 && lds <= 80 * 1024) ? 2 * TRUNET_NUM_CU : TRUNET_NUM_CU, (h->M + mb - 1) / mb);
     auto kern = conv_gemm_kernel<RS, KC, TWO, EPL>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return TRUNET_ELAUNCH;
@@ -596,6 +596,7 @@ int plan_gemm(const trunet_gemm_args* h, GemmPlan* pl) {
             if (fixed + 3 * slot > budget) continue;
             int nb = (int)((budget - fixed) / slot);
             if (nb > 6) nb = 6;
+            if (!(h->epi & TRUNET_EPI_MASK) && fixed + 2 * slot <= budget / 2) nb = (int)((budget / 2 - fixed) / slot);
             pl->rs = rs; pl->kc = kc; pl->nb = nb; pl->lds = fixed + nb * slot; pl->two = two;
             pl->epl = (h->epi & TRUNET_EPI_MASK) ? ((h->epi & TRUNET_EPI_ACCUM) ? 2 : 1) : 0;
             return TRUNET_OK;
@@ -617,7 +618,7 @@ extern "C" int trunet_conv_gemm_plan(const trunet_gemm_args* h, int* rs, int* kc
 
 extern "C" int trunet_conv_gemm_nparts(int M) {
     (void)M;
-    return TRUNET_NUM_CU * 4;   // 256 workgroups x up to 4 column groups
+    return TRUNET_NUM_CU * 8;   // up to 512 workgroups x up to 4 column groups
 }
 
 extern "C" int trunet_conv_gemm(const trunet_gemm_args* h, void* stream) {
