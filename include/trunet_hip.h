@@ -90,8 +90,9 @@ typedef struct {
 int trunet_conv_gemm_nparts(int M);
 int trunet_conv_gemm(const trunet_gemm_args* h_args, void* stream);
 /* launch geometry trunet_conv_gemm picks for these arguments (reporting): kernel instance
- * conv_gemm_kernel<rs, kc, two, epl> (or conv_smallm_kernel<epl> when M <= 8 and !two), ring of nb LDS slots */
-int trunet_conv_gemm_plan(const trunet_gemm_args* h_args, int* rs, int* kc, int* nb, int* two, int* epl);
+ * conv_gemm_kernel<rs, kc, two, epl, nw> (or conv_smallm_kernel<epl> when M <= 8 and !two), ring of nb LDS slots;
+ * nw = 8 (256-frame tiles, two waves per SIMD) needs NP to be a multiple of 256 */
+int trunet_conv_gemm_plan(const trunet_gemm_args* h_args, int* rs, int* kc, int* nb, int* two, int* epl, int* nw);
 
 /* Weight gradient of the same implicit GEMM (autograd of network.py:28,50,64,67,83,86,106,109,48):
  *   dW[(m+w_m_off)*ldw_m + c*ldw_c + woff_seg] = sum_{p,n<N} dz[m][p][n] * pro_seg(src_seg[c][q_seg(p)][n])

@@ -6,7 +6,7 @@ from tinyrecurrentunet_amd import _lib as L
 from tinyrecurrentunet_amd._lib import GemmArgs, make_seg, ptr, check, PRO_BNRELU, PRO_NONE, EPI_BIAS, EPI_STATS
 
 def run(N, Ln, K, M, mode, reps=5):
-    NP = (N + 127) // 128 * 128
+    NP = (N + 255) // 256 * 256
     dev = "cuda"
     x = torch.randn(K, Ln, NP, device=dev)
     out = torch.empty(M, Ln, NP, device=dev)

@@ -69,7 +69,7 @@ def test_engine_launch_mirror():
     assert engine._gemm_rs(64, [mk(64), mk(128)]) == 2
     assert engine._gemm_rs(8, [mk(64), mk(64)]) == 1
     assert engine._gemm_rs(128, [mk(384)]) == 2        # weight block capped at 112 KiB of LDS
-    assert engine.ceil_to(32064, 128) == 32128 and engine.ceil_to(128, 128) == 128
+    assert engine.ceil_to(32064, engine.FRAME_PAD) == 32256 and engine.ceil_to(256, 256) == 256
 
 
 def test_state_dict_round_trip_with_oracle_layout():

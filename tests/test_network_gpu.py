@@ -22,14 +22,16 @@ def _grad_close(g, ref, name, errs=None):
     masks, and BatchNorm makes several of these sums strongly cancelling, so fp32 rounding is
     amplified in EVERY fp32 implementation.  Measured vs the fp64 oracle (N=300,
     tests/gpu_debug_grad_precision.py, relative L2 per tensor, median / max over the 100 tensors):
-    HIP 2.9e-3 / 1.2e-2, torch CPU fp32 4.7e-3 / 6.4e-3, torch GPU fp32 1.2e-2 / 2.5e-2.
-    Bounds: 3e-2 relative L2 for every tensor (the bound that pins the arithmetic) and 8e-2 of max|g| per
+    HIP 2.9e-3 / 1.2e-2, torch CPU fp32 4.7e-3 / 6.4e-3, torch GPU fp32 1.2e-2 / 2.5e-2; over seeds 3,4,5 the
+    medians are HIP 1.0e-2, 6.8e-3, 4.3e-3 vs torch GPU fp32 1.2e-2, 6.4e-3, 4.0e-3 (a single flip near the
+    output perturbs every tensor below it, so the whole vector of errors moves together from run to run).
+    Bounds: 6e-2 relative L2 for every tensor (the bound that pins the arithmetic) and 8e-2 of max|g| per
     element (single elements of the cancelling BatchNorm-gamma sums move by a few % between ANY two
     summation orders, e.g. 256 vs 512 partial rows); callers also bound the median.  Conv biases in front of a BatchNorm have an analytically zero gradient (rounding
     noise in the reference), hence the absolute floors."""
     emax, el2, rmax, rl2 = _errs(g, ref)
     assert emax < 8e-2 * rmax + 2e-3, (name, emax, rmax)
-    assert el2 < 3e-2 * rl2 + 2e-3, (name, el2, rl2)
+    assert el2 < 6e-2 * rl2 + 2e-3, (name, el2, rl2)
     if errs is not None and rmax > 1e-3:
         errs.append(el2 / rl2)
 
@@ -105,7 +107,7 @@ def test_forward_backward_vs_oracle_f64(N):
             continue
         ref_g = pd[pn].grad
         _grad_close(p.grad, ref_g, pn, errs)
-    assert float(np.median(errs)) < 8e-3, float(np.median(errs))
+    assert float(np.median(errs)) < 2.5e-2, float(np.median(errs))
 
 
 def test_state_dict_keys_match_reference_layout():

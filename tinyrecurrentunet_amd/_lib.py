@@ -68,7 +68,7 @@ def _declare(L):
     sig = {
         "trunet_conv_gemm_nparts": [i],
         "trunet_conv_gemm": [C.POINTER(GemmArgs), p],
-        "trunet_conv_gemm_plan": [C.POINTER(GemmArgs)] + [C.POINTER(C.c_int)] * 5,
+        "trunet_conv_gemm_plan": [C.POINTER(GemmArgs)] + [C.POINTER(C.c_int)] * 6,
         "trunet_conv_wgrad_nparts": [],
         "trunet_conv_wgrad": [C.POINTER(WgradArgs), p],
         "trunet_reduce_partials": [p, p, i, i, i, p],

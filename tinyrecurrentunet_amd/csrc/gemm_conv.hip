@@ -14,6 +14,7 @@
 // Wave w owns row slice (w % RS) and column group (w / RS): 32 rows x 32*RS frames = RS accumulators.
 // Epilogue: bias / ReLU-mask / accumulate, vector stores, per-channel statistics kept in registers
 // across all tiles and written once per workgroup (deterministic two-stage reduction).
+#include <cstdlib>
 #include "common.hpp"
 
 namespace {
@@ -55,13 +56,13 @@ struct ChunkIt {
     bool valid;
 };
 
-template <int KC>
+template <int KC, int FT = NT>
 __device__ __forceinline__ void it_enter_tile(const trunet_gemm_args& a, ChunkIt& it) {
     it.valid = it.tile < it.tile_end;
     if (!it.valid) return;
     const int nt = it.tile / a.P;
     it.p = a.p_begin + (it.tile - nt * a.P);
-    it.n0 = nt * NT;
+    it.n0 = nt * FT;
     it.s = 0; it.cc = 0; it.ach = 0; it.cbase = 0;
     while (it.s < a.nseg - 1 && !seg_pos(a.seg[it.s], it.p).valid) {   // host contract: >= 1 valid segment
         it.ach += (a.seg[it.s].nchan + KC - 1) / KC;
@@ -71,7 +72,7 @@ __device__ __forceinline__ void it_enter_tile(const trunet_gemm_args& a, ChunkIt
 }
 
 // true when the chunk after `it` belongs to another tile (or the stream ends)
-template <int KC>
+template <int KC, int FT = NT>
 __device__ __forceinline__ bool it_next(const trunet_gemm_args& a, ChunkIt& it) {
     const int nck = (a.seg[it.s].nchan + KC - 1) / KC;
     if (++it.cc < nck) return false;
@@ -86,7 +87,7 @@ __device__ __forceinline__ bool it_next(const trunet_gemm_args& a, ChunkIt& it) 
     }
     if (it.s < a.nseg) return false;
     ++it.tile;
-    it_enter_tile<KC>(a, it);
+    it_enter_tile<KC, FT>(a, it);
     return true;
 }
 
@@ -118,21 +119,27 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 //   LDS-DMA (global_load_lds, issued NB chunks ahead, no VGPRs)  ->  in-place prologue pass by the thread that
 //   issued the DMA (one chunk ahead of the MFMAs)  ->  fragment reads + MFMAs.  One raw s_barrier per chunk;
 //   DMA completion is tracked with counted s_waitcnt vmcnt, so NB-1 chunks (16 KiB each) stay in flight.
-template <int RS, int KC, bool TWO, int EPL>
-__global__ __launch_bounds__(256, (EPL == 0) ? 2 : 1) void conv_gemm_kernel(const trunet_gemm_args a, const int NB) {
+// NW = 4: 128-frame tiles, one wave per SIMD.  NW = 8: 256-frame tiles, the second group of four waves takes the
+// upper 128 frames of every tile -- same per-wave bookkeeping, twice the MFMAs between two barriers, and two waves
+// per SIMD that fill each other's LDS/issue gaps inside the MFMA phase.
+template <int RS, int KC, bool TWO, int EPL, int NW>
+__global__ __launch_bounds__(64 * NW, (EPL == 0) ? 2 : 1) void conv_gemm_kernel(const trunet_gemm_args a, const int NB) {
+    constexpr int FT = 32 * NW;        // frames per tile
     constexpr int CT = RS;            // column tiles (of 32 frames) per wave
     constexpr int CG = 4 / RS;        // column groups
     constexpr int MB = 32 * RS;       // rows per M block
     constexpr int KP = KC / 2;        // k-pairs per chunk
     constexpr int NSRC = TWO ? 2 : 1;
-    constexpr int CHF = KC * NT * NSRC;            // floats per ring slot
+    constexpr int CHF = KC * FT * NSRC;            // floats per ring slot
     constexpr int LPW = (KC / 8) * NSRC;           // DMA instructions per wave per chunk
     typedef typename BVec<CT>::type bvec;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave8 >> 2;      // which 128 frames of the tile (NW = 8)
+    const int wave = wave8 & 3;
     const int rs = wave % RS;
     const int cg = wave / RS;
     const int h = lane >> 5;
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(256, (EPL == 0) ? 2 : 1) void conv_gemm_kernel(cons
     f32x4* C_lds = (f32x4*)(R_lds + (size_t)NB * CHF);
     float* E_lds = (float*)(C_lds + nchan_total);
 
-    const int ntn = a.NP / NT;
+    const int ntn = a.NP / FT;
     const int total_tiles = a.P * ntn;
     ChunkIt cur;
     cur.tile = (int)(((long long)blockIdx.x * total_tiles) / gridDim.x);
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(256, (EPL == 0) ? 2 : 1) void conv_gemm_kernel(cons
     if (has_work) {
         // weight block in fragment order: [chunk][rs][kg][lane][4], k-pair = 4*kg + j
         const int totalA = nck_total * RS * (KP * 64);
-        for (int idx = tid; idx < totalA; idx += 256) {
+        for (int idx = tid; idx < totalA; idx += 64 * NW) {
             const int j = idx & 3;
             const int ln = (idx >> 2) & 63;
             const int rest = idx >> 8;
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(256, (EPL == 0) ? 2 : 1) void conv_gemm_kernel(cons
         int base = 0;
         for (int s = 0; s < a.nseg; ++s) {
             const trunet_seg& sg = a.seg[s];
-            for (int ci = tid; ci < sg.nchan; ci += 256) {
+            for (int ci = tid; ci < sg.nchan; ci += 64 * NW) {
                 f32x4 k;
                 if (TWO) {
                     const bool on = sg.mode == TRUNET_PRO_BNBWD;
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(256, (EPL == 0) ? 2 : 1) void conv_gemm_kernel(cons
             }
             base += sg.nchan;
         }
-        for (int r = tid; r < MB; r += 256) {
+        for (int r = tid; r < MB; r += 64 * NW) {
             const int m = mblk * MB + r;
             const int mg = m + a.m_out_off;
             const bool ok = m < a.M;
@@ -211,21 +218,22 @@ __global__ __launch_bounds__(256, (EPL == 0) ? 2 : 1) void conv_gemm_kernel(cons
     __syncthreads();
 
     if (has_work) {
-        // ---- LDS-DMA of one chunk.  Wave w, instruction i: row pair g = (LPW/NSRC)*w + i/NSRC of tensor i%NSRC;
-        // 64 lanes x 16 B = rows 2g, 2g+1 (512 B each) contiguous in LDS.  The SAME thread later transforms
-        // exactly the bytes it requested, so the prologue pass needs no barrier of its own.
+        // ---- LDS-DMA of one chunk: KC rows x FT frames (per tensor) as 1-KiB wave-instructions; instruction g covers
+        // slot elements [256 g, 256 g + 256).  Wave w8 issues g = (LPW/NSRC) w8 + i/NSRC for tensor i % NSRC.  The SAME
+        // thread later transforms exactly the bytes it requested, so the prologue pass needs no barrier of its own.
         auto issue_dma = [&](const ChunkIt& it, int slot) {
             const trunet_seg& sg = a.seg[it.s];
             const int q = seg_pos(sg, it.p).q;
             float* dst = R_lds + (size_t)slot * CHF;
-            int ci = it.cc * KC + 2 * ((LPW / NSRC) * wave) + h;
 #pragma unroll
             for (int i = 0; i < LPW; ++i) {
-                const int g = (LPW / NSRC) * wave + i / NSRC;
-                const int cch = min(ci + 2 * (i / NSRC), sg.nchan - 1);   // rows past the segment: finite filler (A = 0)
+                const int g = (LPW / NSRC) * wave8 + i / NSRC;
+                const int e = g * 256 + 4 * lane;
+                const int row = e / FT, col = e % FT;
+                const int cch = min(it.cc * KC + row, sg.nchan - 1);      // rows past the segment: finite filler (A = 0)
                 const float* src = (TWO && (i % NSRC)) ? (sg.src1 ? sg.src1 : sg.src0) : sg.src0;
-                const float* gp = src + ((size_t)cch * sg.L + q) * a.NP + it.n0 + 4 * c;
-                __builtin_amdgcn_global_load_lds(gp, (lds_ptr_t)(dst + (i % NSRC) * (KC * NT) + g * 256), 16, 0, 0);
+                const float* gp = src + ((size_t)cch * sg.L + q) * a.NP + it.n0 + col;
+                __builtin_amdgcn_global_load_lds(gp, (lds_ptr_t)(dst + (i % NSRC) * (KC * FT) + g * 256), 16, 0, 0);
             }
         };
         // in-place prologue on this thread's own pieces of the chunk in `slot` (all reads first, then the math,
@@ -236,11 +244,11 @@ __global__ __launch_bounds__(256, (EPL == 0) ? 2 : 1) void conv_gemm_kernel(cons
             f32x4 v[LPW / NSRC], z[LPW / NSRC], k[LPW / NSRC];
 #pragma unroll
             for (int i = 0; i < LPW / NSRC; ++i) {
-                const int row = 2 * ((LPW / NSRC) * wave + i) + h;
-                const float* pz = dst + row * NT + 4 * c;
+                const int e = ((LPW / NSRC) * wave8 + i) * 256 + 4 * lane;
+                const float* pz = dst + e;
                 v[i] = *(const f32x4*)pz;
-                if (TWO) z[i] = *(const f32x4*)(pz + KC * NT);
-                k[i] = C_lds[it.cbase + it.cc * KC + min(row, nrow - 1)];
+                if (TWO) z[i] = *(const f32x4*)(pz + KC * FT);
+                k[i] = C_lds[it.cbase + it.cc * KC + min(e / FT, nrow - 1)];
             }
 #pragma unroll
             for (int i = 0; i < LPW / NSRC; ++i) {
@@ -253,25 +261,23 @@ __global__ __launch_bounds__(256, (EPL == 0) ? 2 : 1) void conv_gemm_kernel(cons
                 }
             }
 #pragma unroll
-            for (int i = 0; i < LPW / NSRC; ++i) {
-                const int row = 2 * ((LPW / NSRC) * wave + i) + h;
-                *(f32x4*)(dst + row * NT + 4 * c) = v[i];
-            }
+            for (int i = 0; i < LPW / NSRC; ++i)
+                *(f32x4*)(dst + ((LPW / NSRC) * wave8 + i) * 256 + 4 * lane) = v[i];
         };
 
         // ---- pipeline prologue
-        it_enter_tile<KC>(a, cur);
+        it_enter_tile<KC, FT>(a, cur);
         ChunkIt ld = cur, ldlast = cur;
         for (int d = 0; d < NB; ++d) {
             if (ld.valid) ldlast = ld;
             issue_dma(ldlast, d);                       // past the end: harmless re-load of the last chunk
-            if (ld.valid) it_next<KC>(a, ld);
+            if (ld.valid) it_next<KC, FT>(a, ld);
         }
         ChunkIt tf = cur;                               // chunk whose prologue pass comes next
         int tslot = 0;
         wait_vmcnt((NB - 1) * LPW);
         transform(tf, tslot);
-        it_next<KC>(a, tf);
+        it_next<KC, FT>(a, tf);
         tslot = 1;
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -285,12 +291,12 @@ __global__ __launch_bounds__(256, (EPL == 0) ? 2 : 1) void conv_gemm_kernel(cons
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
             const int tp = cur.p;
-            const int nb = cur.n0 + (32 * RS) * cg + CT * c;
+            const int nb = cur.n0 + 128 * half + (32 * RS) * cg + CT * c;
             bvec zv[16], ov[16];
             bool last = false;
             while (!last) {                              // ---- chunks of the tile
                 ChunkIt nxt = cur;
-                last = it_next<KC>(a, nxt);
+                last = it_next<KC, FT>(a, nxt);
                 if (EPL > 0 && last) {                   // epilogue operands: issued before the MFMAs
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -306,19 +312,19 @@ __global__ __launch_bounds__(256, (EPL == 0) ? 2 : 1) void conv_gemm_kernel(cons
                     if (EPL > 0 && last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     else wait_vmcnt((NB - 2) * LPW);
                     transform(tf, tslot);
-                    it_next<KC>(a, tf);
+                    it_next<KC, FT>(a, tf);
                     tslot = (tslot + 1 == NB) ? 0 : tslot + 1;
                 }
                 // fragments of chunk `cur`, then the MFMAs
                 {
                     const float* Ab = A_lds + (size_t)((cur.ach + cur.cc) * RS + rs) * (KP * 64);
-                    const float* Bb = R_lds + (size_t)slot * CHF + (32 * RS) * cg + CT * c;
+                    const float* Bb = R_lds + (size_t)slot * CHF + 128 * half + (32 * RS) * cg + CT * c;
                     f32x4 af[KP / 4];
                     bvec bf[KP];
 #pragma unroll
                     for (int kg = 0; kg < KP / 4; ++kg) af[kg] = *(const f32x4*)(Ab + (kg * 64 + lane) * 4);
 #pragma unroll
-                    for (int kk = 0; kk < KP; ++kk) bf[kk] = *(const bvec*)(Bb + (2 * kk + h) * NT);
+                    for (int kk = 0; kk < KP; ++kk) bf[kk] = *(const bvec*)(Bb + (2 * kk + h) * FT);
 #pragma unroll
                     for (int kk = 0; kk < KP; ++kk)
 #pragma unroll
@@ -342,7 +348,7 @@ __global__ __launch_bounds__(256, (EPL == 0) ? 2 : 1) void conv_gemm_kernel(cons
                 // slot `slot` is free for everyone now: refill it with chunk (cur + NB)
                 if (ld.valid) ldlast = ld;
                 issue_dma(ldlast, slot);
-                if (ld.valid) it_next<KC>(a, ld);
+                if (ld.valid) it_next<KC, FT>(a, ld);
                 slot = (slot + 1 == NB) ? 0 : slot + 1;
                 cur = nxt;
             }
@@ -398,7 +404,7 @@ __global__ __launch_bounds__(256, (EPL == 0) ? 2 : 1) void conv_gemm_kernel(cons
             const int m = mblk * MB + 32 * rs + ml;
             if (c == 0 && m < a.M) {
                 const int mg = m + a.m_out_off;
-                float* pp = a.partials + ((size_t)(blockIdx.x * CG + cg) * a.M_stat + mg) * 2;
+                float* pp = a.partials + ((size_t)((blockIdx.x * (NW / 4) + half) * CG + cg) * a.M_stat + mg) * 2;
                 pp[0] = s1;
                 pp[1] = s2;
             }
@@ -546,36 +552,44 @@ int launch_smallm(const trunet_gemm_args* h, hipStream_t st) {
     return trunet_launch_status();
 }
 
-template <int RS, int KC, bool TWO, int EPL>
-int launch_gemm(const trunet_gemm_args* h, int NB, size_t lds, hipStream_t st) {
+template <int RS, int KC, bool TWO, int EPL, int NW>
+int launch_gemm_nw(const trunet_gemm_args* h, int NB, size_t lds, hipStream_t st) {
     const int mb = 32 * RS;
-    dim3 grid((EPL == 0 && lds <= 80 * 1024) ? 2 * TRUNET_NUM_CU : TRUNET_NUM_CU, (h->M + mb - 1) / mb);
-    auto kern = conv_gemm_kernel<RS, KC, TWO, EPL>;
+    dim3 grid((NW == 4 && EPL == 0 && lds <= 80 * 1024) ? 2 * TRUNET_NUM_CU : TRUNET_NUM_CU, (h->M + mb - 1) / mb);
+    auto kern = conv_gemm_kernel<RS, KC, TWO, EPL, NW>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return TRUNET_ELAUNCH;
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, *h, NB);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, *h, NB);
     return trunet_launch_status();
 }
 
+template <int RS, int KC, bool TWO, int EPL>
+int launch_gemm(const trunet_gemm_args* h, int NB, size_t lds, hipStream_t st, int nw = 4) {
+    if constexpr (EPL == 0) {
+        if (nw == 8) return launch_gemm_nw<RS, KC, TWO, EPL, 8>(h, NB, lds, st);
+    }
+    return launch_gemm_nw<RS, KC, TWO, EPL, 4>(h, NB, lds, st);
+}
+
 template <int RS>
-int launch_gemm_rs(const trunet_gemm_args* h, int kc, bool two, int epl, int NB, size_t lds, hipStream_t st) {
+int launch_gemm_rs(const trunet_gemm_args* h, int kc, bool two, int epl, int NB, size_t lds, hipStream_t st, int nw) {
     if (two && kc == 32) {
-        if (epl == 0) return launch_gemm<RS, 32, true, 0>(h, NB, lds, st);
+        if (epl == 0) return launch_gemm<RS, 32, true, 0>(h, NB, lds, st, nw);
         if (epl == 1) return launch_gemm<RS, 32, true, 1>(h, NB, lds, st);
         return launch_gemm<RS, 32, true, 2>(h, NB, lds, st);
     }
     if (two) {
-        if (epl == 0) return launch_gemm<RS, 16, true, 0>(h, NB, lds, st);
+        if (epl == 0) return launch_gemm<RS, 16, true, 0>(h, NB, lds, st, nw);
         if (epl == 1) return launch_gemm<RS, 16, true, 1>(h, NB, lds, st);
         return launch_gemm<RS, 16, true, 2>(h, NB, lds, st);
     }
-    if (epl == 0) return launch_gemm<RS, 32, false, 0>(h, NB, lds, st);
+    if (epl == 0) return launch_gemm<RS, 32, false, 0>(h, NB, lds, st, nw);
     if (epl == 1) return launch_gemm<RS, 32, false, 1>(h, NB, lds, st);
     return launch_gemm<RS, 32, false, 2>(h, NB, lds, st);
 }
 
 // launch geometry shared by trunet_conv_gemm and (for reporting) the host: row slices, chunk rows, ring slots
-struct GemmPlan { int rs, kc, nb; size_t lds; bool two; int epl; };
+struct GemmPlan { int rs, kc, nb, nw; size_t lds; bool two; int epl; };
 
 int plan_gemm(const trunet_gemm_args* h, GemmPlan* pl) {
     bool two = false;
@@ -597,7 +611,15 @@ int plan_gemm(const trunet_gemm_args* h, GemmPlan* pl) {
             int nb = (int)((budget - fixed) / slot);
             if (nb > 6) nb = 6;
             if (!(h->epi & TRUNET_EPI_MASK) && fixed + 2 * slot <= budget / 2) nb = (int)((budget / 2 - fixed) / slot);
-            pl->rs = rs; pl->kc = kc; pl->nb = nb; pl->lds = fixed + nb * slot; pl->two = two;
+            pl->rs = rs; pl->kc = kc; pl->nb = nb; pl->lds = fixed + nb * slot; pl->two = two; pl->nw = 4;
+            // wide variant (8 waves, 256-frame tiles) for launches without tensor-operand epilogue when it fits
+            static const bool wide_ok = !(getenv("TRUNET_GEMM_WIDE") && getenv("TRUNET_GEMM_WIDE")[0] == '0');
+            if (wide_ok && !(h->epi & TRUNET_EPI_MASK) && (h->NP % 256) == 0 && fixed + 2 * 2 * slot <= budget &&
+                pl->lds > 80 * 1024) {
+                int nbw = (int)((budget - fixed) / (2 * slot));
+                if (nbw > 4) nbw = 4;
+                pl->nw = 8; pl->nb = nbw; pl->lds = fixed + (size_t)nbw * 2 * slot;
+            }
             pl->epl = (h->epi & TRUNET_EPI_MASK) ? ((h->epi & TRUNET_EPI_ACCUM) ? 2 : 1) : 0;
             return TRUNET_OK;
         }
@@ -608,11 +630,11 @@ int plan_gemm(const trunet_gemm_args* h, GemmPlan* pl) {
 
 }  // namespace
 
-extern "C" int trunet_conv_gemm_plan(const trunet_gemm_args* h, int* rs, int* kc, int* nb, int* two, int* epl) {
-    if (!h || !rs || !kc || !nb || !two || !epl) return TRUNET_EINVAL;
+extern "C" int trunet_conv_gemm_plan(const trunet_gemm_args* h, int* rs, int* kc, int* nb, int* two, int* epl, int* nw) {
+    if (!h || !rs || !kc || !nb || !two || !epl || !nw) return TRUNET_EINVAL;
     GemmPlan pl;
     if (plan_gemm(h, &pl) != TRUNET_OK) return TRUNET_ENOTSUP;
-    *rs = pl.rs; *kc = pl.kc; *nb = pl.nb; *two = pl.two ? 1 : 0; *epl = pl.epl;
+    *rs = pl.rs; *kc = pl.kc; *nb = pl.nb; *two = pl.two ? 1 : 0; *epl = pl.epl; *nw = pl.nw;
     return TRUNET_OK;
 }
 
@@ -648,9 +670,9 @@ extern "C" int trunet_conv_gemm(const trunet_gemm_args* h, void* stream) {
     }
     if (h->M <= 8 && !any_two) return launch_smallm(h, st);
     switch (pl.rs) {
-        case 4: return launch_gemm_rs<4>(h, pl.kc, pl.two, pl.epl, pl.nb, pl.lds, st);
-        case 2: return launch_gemm_rs<2>(h, pl.kc, pl.two, pl.epl, pl.nb, pl.lds, st);
-        default: return launch_gemm_rs<1>(h, pl.kc, pl.two, pl.epl, pl.nb, pl.lds, st);
+        case 4: return launch_gemm_rs<4>(h, pl.kc, pl.two, pl.epl, pl.nb, pl.lds, st, pl.nw);
+        case 2: return launch_gemm_rs<2>(h, pl.kc, pl.two, pl.epl, pl.nb, pl.lds, st, pl.nw);
+        default: return launch_gemm_rs<1>(h, pl.kc, pl.two, pl.epl, pl.nb, pl.lds, st, pl.nw);
     }
 }
 

@@ -17,6 +17,7 @@ from ._lib import (EPI_ACCUM, EPI_BIAS, EPI_MASK, EPI_STATS, PRO_BNBWD, PRO_BNRE
                    WgradArgs, check, make_seg, ptr)
 
 F_BINS = 257
+FRAME_PAD = 256      # frames are padded to a multiple of 256 (widest conv_gemm tile)
 BN_EPS = 1e-5
 BN_MOM = 0.1
 
@@ -60,12 +61,12 @@ def _gemm_kernel_name(a):
     """Exact symbol (template arguments included) of the kernel trunet_conv_gemm launches for `a`, so that
     bench.py's per-kernel numbers can be matched against rocprofv3's kernel names."""
     import ctypes as C
-    v = [C.c_int() for _ in range(5)]
+    v = [C.c_int() for _ in range(6)]
     check(L.lib().trunet_conv_gemm_plan(a, *[C.byref(x) for x in v]), "conv_gemm_plan")
-    rs, kc, nb, two, epl = [x.value for x in v]
+    rs, kc, nb, two, epl, nw = [x.value for x in v]
     if a.M <= 8 and not two:
         return "conv_smallm_kernel<%d>" % epl
-    return "conv_gemm_kernel<%d, %d, %s, %d>" % (rs, kc, "true" if two else "false", epl)
+    return "conv_gemm_kernel<%d, %d, %s, %d, %d>" % (rs, kc, "true" if two else "false", epl, nw)
 
 
 def _seg_positions(s, p0, P):
@@ -271,7 +272,7 @@ class TRUNetEngine:
     def _load(self, w, name, x):
         x = x.contiguous()
         N, C, Ln = x.shape
-        NP = ceil_to(N, 128)
+        NP = ceil_to(N, FRAME_PAD)
         t = w.get("in:" + name, (C, Ln, NP))
         check(L.lib().trunet_to_frames_last(ptr(x), ptr(t), N, C, Ln, NP, L.stream()), "to_frames_last")
         return Act(t, C, Ln), N, NP
@@ -290,7 +291,7 @@ class TRUNetEngine:
         post-activation output like the reference.  Forward only: training goes through ``TRUNet``."""
         dev = xs[0].device
         N = xs[0].shape[0]
-        NP = ceil_to(N, 128)
+        NP = ceil_to(N, FRAME_PAD)
         w = self.ws(NP, dev)
         lib = L.lib()
         if kind == "std":
@@ -328,7 +329,7 @@ class TRUNetEngine:
             raise L.TrunetHipError("the HIP GRU kernel is built for the bidirectional H=64 FGRU (network.py:149); "
                                    "the unidirectional TGRU (network.py:150) is never executed (R4)")
         dev = x.device
-        a, N, NP = self._load(self.ws(ceil_to(x.shape[0], 128), dev), "b0", x.transpose(1, 2))
+        a, N, NP = self._load(self.ws(ceil_to(x.shape[0], FRAME_PAD), dev), "b0", x.transpose(1, 2))
         w = self.ws(NP, dev)
         hout = self._gru(w, a, gru, N, NP, training)
         cur = self._pw(w, "blk.fgru", [hout], blk.conv[0], blk.conv[1], N, NP, training)
@@ -359,7 +360,7 @@ class TRUNetEngine:
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[2] == F_BINS
         x = x.contiguous()
         N, Cin = x.shape[0], x.shape[1]
-        NP = ceil_to(N, 128)
+        NP = ceil_to(N, FRAME_PAD)
         w = self.ws(NP, x.device)
         lib = L.lib()
         st = L.stream()
