@@ -691,7 +691,7 @@ extern "C" int trunet_conv_gemm(const trunet_gemm_args* h, void* stream) {
 namespace {
 
 constexpr int WFC = 32;         // frames per tile
-constexpr int MAXT = 5;         // accumulator tiles per wave
+constexpr int MAXT = 3;         // accumulator tiles per wave (8 waves)
 constexpr int WGRAD_GRID = TRUNET_NUM_CU;
 
 __device__ __forceinline__ void wait_vmcnt_any(int n) {
@@ -710,7 +710,7 @@ __device__ __forceinline__ void wait_vmcnt_any(int n) {
 __device__ __forceinline__ int wg_off(int r, int pc) { return r * WFC + 4 * (pc ^ ((r >> 1) & 7)); }
 
 template <bool TWO>
-__global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const trunet_wgrad_args a, const int NB, const int nvmax,
+__global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const trunet_wgrad_args a, const int NB, const int nvmax,
                                                             const int rows) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -721,9 +721,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const trunet_wgrad_a
     const int MA = (a.M + 31) & ~31;          // padded dz rows
     const int nrt = MA / 32;
     const int DZR = TWO ? 2 * MA : MA;        // rows of the dz block (dy [+ z])
-    const int PPW = MA / 32;                  // dz row groups (8 rows x 128 B per DMA instruction) per wave
-    const int SPW = (rows - DZR) / 32;        // staged-segment row groups per wave
-    const int LPW = PPW * (TWO ? 2 : 1) + SPW;   // DMA instructions per wave per tile
+    // 8 waves (two per SIMD).  DMA instructions (8 rows x 128 B each) are dealt round-robin: wave w issues the dz
+    // row groups g = w + 8 i < Gd and the staged-segment row groups g = w + 8 i < Gs.
+    const int Gd = MA / 8;
+    const int Gs = (rows - DZR) / 8;
+    const int PPW = (Gd - wave + 7) / 8;      // this wave's dz row groups
+    const int SPW = (Gs - wave + 7) / 8;      // this wave's staged-segment row groups
+    const int LPW = PPW * (TWO ? 2 : 1) + SPW;   // this wave's DMA instructions per tile
     const int SLOT = rows * WFC;              // floats per slot
 
     float* R_lds = smem;
@@ -732,7 +736,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const trunet_wgrad_a
     for (int s = 0; s < a.nseg; ++s) ntot += a.seg[s].nchan;
     f32x4* CB = CA + MA;                                     // [sum nchan] activation coefficients
 
-    for (int r = tid; r < MA; r += 256) {
+    for (int r = tid; r < MA; r += 512) {
         const int ch = min(r, a.M - 1) + a.a_m_off;
         f32x4 k = {1.f, 0.f, 0.f, 0.f};
         if (TWO) { k[0] = a.ac0[ch]; k[1] = a.ac1[ch]; k[2] = a.ac2[ch]; }
@@ -743,7 +747,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const trunet_wgrad_a
         int base = 0;
         for (int s = 0; s < a.nseg; ++s) {
             const trunet_seg& sg = a.seg[s];
-            for (int ci = tid; ci < sg.nchan; ci += 256) {
+            for (int ci = tid; ci < sg.nchan; ci += 512) {
                 const bool on = sg.mode == TRUNET_PRO_BNRELU;
                 f32x4 k = {on ? sg.c0[ci] : 1.f, on ? sg.c1[ci] : 0.f, on ? 0.f : -3.0e38f, 0.f};
                 CB[base + ci] = k;
@@ -752,7 +756,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const trunet_wgrad_a
         }
     }
 
-    // global tile enumeration of the OUTPUT: g -> (seg, ctile, rt), rt fastest; wave w owns g = w, w+4, ...
+    // global tile enumeration of the OUTPUT: g -> (seg, ctile, rt), rt fastest; wave w owns g = w, w+8, ...
     int ntile_seg[TRUNET_MAX_SEG];
     int G = 0;
 #pragma unroll
@@ -763,7 +767,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const trunet_wgrad_a
     int t_seg[MAXT], t_ct[MAXT], t_rt[MAXT];
 #pragma unroll
     for (int i = 0; i < MAXT; ++i) {
-        int g = wave + 4 * i;
+        int g = wave + 8 * i;
         t_seg[i] = -1; t_ct[i] = 0; t_rt[i] = 0;
         if (g < G) {
 #pragma unroll
@@ -782,9 +786,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const trunet_wgrad_a
     for (int i = 0; i < MAXT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    float bsum[6];
+    float bsum[3];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) bsum[i] = 0.f;
+    for (int i = 0; i < 3; ++i) bsum[i] = 0.f;
 
     const int nfc = a.NP / WFC;
     const int total_tiles = a.P * nfc;
@@ -832,15 +836,15 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const trunet_wgrad_a
                 }
             }
             // per-lane source pointers (frame 0 of this lane's row, logical piece folded in) and coefficient rows
-            const float* pd[6];      // dy rows
-            const float* pzr[6];     // z rows (TWO)
-            const float* ps[10];     // staged-segment rows
-            int cidx[10];            // coefficient index of the staged-segment rows
+            const float* pd[3];      // dy rows
+            const float* pzr[3];     // z rows (TWO)
+            const float* ps[5];      // staged-segment rows
+            int cidx[5];             // coefficient index of the staged-segment rows
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
+            for (int i = 0; i < 3; ++i) {
                 pd[i] = a.a0; pzr[i] = a.a0;
                 if (i < PPW) {
-                    const int r = 8 * (wave * PPW + i) + (lane >> 3);
+                    const int r = 8 * (wave + 8 * i) + (lane >> 3);
                     const int lc = pc ^ ((r >> 1) & 7);
                     const int m = min(r, a.M - 1) + a.a_m_off;
                     const size_t off = ((size_t)m * a.a_L + p + a.a_pos_off) * a.NP + 4 * lc;
@@ -849,10 +853,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const trunet_wgrad_a
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 10; ++i) {
+            for (int i = 0; i < 5; ++i) {
                 ps[i] = a.a0; cidx[i] = 0;
                 if (i < SPW) {
-                    const int g = wave * SPW + i;
+                    const int g = wave + 8 * i;
                     int rb = 0, sidx = sl[0], q = sq[0], ch0 = 0;
 #pragma unroll
                     for (int j = 0; j < TRUNET_MAX_SEG; ++j) {
@@ -877,17 +881,17 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const trunet_wgrad_a
                 const int n0 = (t - pi * nfc) * WFC;
                 float* dst = R_lds + (size_t)slot * SLOT;
 #pragma unroll
-                for (int i = 0; i < 6; ++i) {
+                for (int i = 0; i < 3; ++i) {
                     if (i < PPW) {
-                        const int g = wave * PPW + i;
+                        const int g = wave + 8 * i;
                         __builtin_amdgcn_global_load_lds(pd[i] + n0, (lds_ptr_t)(dst + g * 256), 16, 0, 0);
                         if (TWO) __builtin_amdgcn_global_load_lds(pzr[i] + n0, (lds_ptr_t)(dst + (MA / 8 + g) * 256), 16, 0, 0);
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < 10; ++i) {
+                for (int i = 0; i < 5; ++i) {
                     if (i < SPW) {
-                        const int g = wave * SPW + i;
+                        const int g = wave + 8 * i;
                         __builtin_amdgcn_global_load_lds(ps[i] + n0, (lds_ptr_t)(dst + (DZR / 8 + g) * 256), 16, 0, 0);
                     }
                 }
@@ -897,9 +901,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const trunet_wgrad_a
                 const int n0 = (t - pi * nfc) * WFC;
                 float* dst = R_lds + (size_t)slot * SLOT;
 #pragma unroll
-                for (int i = 0; i < 6; ++i) {
+                for (int i = 0; i < 3; ++i) {
                     if (i < PPW) {
-                        const int r = 8 * (wave * PPW + i) + (lane >> 3);
+                        const int r = 8 * (wave + 8 * i) + (lane >> 3);
                         const int lc = pc ^ ((r >> 1) & 7);
                         float* pz = dst + r * WFC + 4 * pc;
                         f32x4 v = *(f32x4*)pz;
@@ -923,10 +927,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const trunet_wgrad_a
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < 10; ++i) {
+                for (int i = 0; i < 5; ++i) {
                     if (i < SPW) {
                         const f32x4 k = CB[cidx[i]];
-                        float* pz = dst + (DZR + 8 * (wave * SPW + i) + (lane >> 3)) * WFC + 4 * pc;
+                        float* pz = dst + (DZR + 8 * (wave + 8 * i) + (lane >> 3)) * WFC + 4 * pc;
                         f32x4 v = *(f32x4*)pz;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], k[0], k[1]), k[2]);
@@ -1007,12 +1011,12 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const trunet_wgrad_a
     }
     if (a.b_partials) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < 3; ++i) {
             float v = bsum[i];
             v += __shfl_xor(v, 4);
             v += __shfl_xor(v, 2);
             v += __shfl_xor(v, 1);
-            const int row = 8 * (wave * PPW + i) + (lane >> 3);
+            const int row = 8 * (wave + 8 * i) + (lane >> 3);
             if ((lane & 7) == 0 && i < PPW && row < a.M)
                 a.b_partials[(size_t)blockIdx.x * a.b_stride + a.b_off + row] = v;
         }
@@ -1065,21 +1069,21 @@ extern "C" int trunet_conv_wgrad(const trunet_wgrad_args* h, void* stream) {
         segrows = nvmax * maxsrp;
     }
     const int rows = MA * (two ? 2 : 1) + segrows;
-    if (tiles > 4 * MAXT || rows > 512 || MA > 6 * 32) return TRUNET_ENOTSUP;
+    if (tiles > 8 * MAXT || rows > 512 || MA > 6 * 32 || rows - MA * (two ? 2 : 1) > 320) return TRUNET_ENOTSUP;
     const size_t slot = (size_t)rows * WFC * sizeof(float);
     const size_t fixed = (size_t)(MA + ntot) * sizeof(f32x4);
     int NB = (int)((160 * 1024 - fixed) / slot);
     if (NB > 4) NB = 4;
     if (NB < 2) return TRUNET_ENOTSUP;
-    if ((NB - 1) * (rows / 32) > 60) return TRUNET_ENOTSUP;
+    if ((NB - 1) * ((MA / 8 + 7) / 8 * (two ? 2 : 1) + ((rows - MA * (two ? 2 : 1)) / 8 + 7) / 8) > 60) return TRUNET_ENOTSUP;
     const size_t lds = fixed + NB * slot;
     hipStream_t st = (hipStream_t)stream;
     if (two) {
         if (hipFuncSetAttribute((const void*)conv_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return TRUNET_ELAUNCH;
-        hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3(WGRAD_GRID), dim3(256), lds, st, *h, NB, nvmax, rows);
+        hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3(WGRAD_GRID), dim3(512), lds, st, *h, NB, nvmax, rows);
     } else {
         if (hipFuncSetAttribute((const void*)conv_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return TRUNET_ELAUNCH;
-        hipLaunchKernelGGL(conv_wgrad_kernel<false>, dim3(WGRAD_GRID), dim3(256), lds, st, *h, NB, nvmax, rows);
+        hipLaunchKernelGGL(conv_wgrad_kernel<false>, dim3(WGRAD_GRID), dim3(512), lds, st, *h, NB, nvmax, rows);
     }
     return trunet_launch_status();
 }
