@@ -123,7 +123,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // upper 128 frames of every tile -- same per-wave bookkeeping, twice the MFMAs between two barriers, and two waves
 // per SIMD that fill each other's LDS/issue gaps inside the MFMA phase.
 template <int RS, int KC, bool TWO, int EPL, int NW>
-__global__ __launch_bounds__(64 * NW, (EPL == 0) ? 2 : 1) void conv_gemm_kernel(const trunet_gemm_args a, const int NB) {
+__global__ __launch_bounds__(64 * NW, (EPL == 0 || NW == 8) ? 2 : 1) void conv_gemm_kernel(const trunet_gemm_args a, const int NB) {
     constexpr int FT = 32 * NW;        // frames per tile
     constexpr int CT = RS;            // column tiles (of 32 frames) per wave
     constexpr int CG = 4 / RS;        // column groups
@@ -565,7 +565,7 @@ int launch_gemm_nw(const trunet_gemm_args* h, int NB, size_t lds, hipStream_t st
 
 template <int RS, int KC, bool TWO, int EPL>
 int launch_gemm(const trunet_gemm_args* h, int NB, size_t lds, hipStream_t st, int nw = 4) {
-    if constexpr (EPL == 0) {
+    if constexpr (EPL == 0 || (EPL == 1 && RS <= 2)) {
         if (nw == 8) return launch_gemm_nw<RS, KC, TWO, EPL, 8>(h, NB, lds, st);
     }
     return launch_gemm_nw<RS, KC, TWO, EPL, 4>(h, NB, lds, st);
@@ -575,17 +575,17 @@ template <int RS>
 int launch_gemm_rs(const trunet_gemm_args* h, int kc, bool two, int epl, int NB, size_t lds, hipStream_t st, int nw) {
     if (two && kc == 32) {
         if (epl == 0) return launch_gemm<RS, 32, true, 0>(h, NB, lds, st, nw);
-        if (epl == 1) return launch_gemm<RS, 32, true, 1>(h, NB, lds, st);
-        return launch_gemm<RS, 32, true, 2>(h, NB, lds, st);
+        if (epl == 1) return launch_gemm<RS, 32, true, 1>(h, NB, lds, st, nw);
+        return launch_gemm<RS, 32, true, 2>(h, NB, lds, st, nw);
     }
     if (two) {
         if (epl == 0) return launch_gemm<RS, 16, true, 0>(h, NB, lds, st, nw);
-        if (epl == 1) return launch_gemm<RS, 16, true, 1>(h, NB, lds, st);
-        return launch_gemm<RS, 16, true, 2>(h, NB, lds, st);
+        if (epl == 1) return launch_gemm<RS, 16, true, 1>(h, NB, lds, st, nw);
+        return launch_gemm<RS, 16, true, 2>(h, NB, lds, st, nw);
     }
     if (epl == 0) return launch_gemm<RS, 32, false, 0>(h, NB, lds, st, nw);
-    if (epl == 1) return launch_gemm<RS, 32, false, 1>(h, NB, lds, st);
-    return launch_gemm<RS, 32, false, 2>(h, NB, lds, st);
+    if (epl == 1) return launch_gemm<RS, 32, false, 1>(h, NB, lds, st, nw);
+    return launch_gemm<RS, 32, false, 2>(h, NB, lds, st, nw);
 }
 
 // launch geometry shared by trunet_conv_gemm and (for reporting) the host: row slices, chunk rows, ring slots
@@ -614,8 +614,10 @@ int plan_gemm(const trunet_gemm_args* h, GemmPlan* pl) {
             pl->rs = rs; pl->kc = kc; pl->nb = nb; pl->lds = fixed + nb * slot; pl->two = two; pl->nw = 4;
             // wide variant (8 waves, 256-frame tiles) for launches without tensor-operand epilogue when it fits
             static const bool wide_ok = !(getenv("TRUNET_GEMM_WIDE") && getenv("TRUNET_GEMM_WIDE")[0] == '0');
-            if (wide_ok && !(h->epi & TRUNET_EPI_MASK) && (h->NP % 256) == 0 && fixed + 2 * 2 * slot <= budget &&
-                pl->lds > 80 * 1024) {
+            const int epl_w = (h->epi & TRUNET_EPI_MASK) ? ((h->epi & TRUNET_EPI_ACCUM) ? 2 : 1) : 0;
+            const bool wide_kind = epl_w == 0 || (epl_w == 1 && rs <= 2);     // register budget of two waves per SIMD
+            if (wide_ok && wide_kind && (h->NP % 256) == 0 && fixed + 2 * 2 * slot <= budget &&
+                (pl->lds > 80 * 1024 || epl_w > 0)) {
                 int nbw = (int)((budget - fixed) / (2 * slot));
                 if (nbw > 4) nbw = 4;
                 pl->nw = 8; pl->nb = nbw; pl->lds = fixed + (size_t)nbw * 2 * slot;
