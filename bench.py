@@ -95,20 +95,39 @@ def streaming(args, dev):
     torch.manual_seed(0)
     net = hn.TRUNet(input_size=4).to(dev).eval()
     x = torch.randn(streams, 4, 257, device=dev)
+    graphed = False
     with torch.no_grad():
-        for _ in range(args.warmup):
+        for _ in range(max(args.warmup, 2)):
             net(x)
+        torch.cuda.synchronize()
+        # the ~70 launches of one forward are launch-bound at this size: replay them as one hipGraph
+        g = None
+        if not os.environ.get("TRUNET_NO_GRAPH"):
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    y = net(x)
+                g.replay()
+                torch.cuda.synchronize()
+                graphed = True
+            except Exception as e:       # capture is an optimisation, not a requirement
+                print("[streaming] graph capture unavailable: %r" % (e,), file=sys.stderr)
+                g = None
         torch.cuda.synchronize()
         t0 = time.time()
         for _ in range(args.steps):
-            x = torch.randn(streams, 4, 257, device=dev)
-            y = net(x)
+            if g is not None:
+                x.normal_()                 # fresh frame of every stream, in place (rt.py:21 draws a new randn)
+                g.replay()
+            else:
+                x = torch.randn(streams, 4, 257, device=dev)
+                y = net(x)
         torch.cuda.synchronize()
     dt = (time.time() - t0) / args.steps
     out = {"metric": "streaming forward real-time factor (1024 streams x 1 frame)", "value": round(streams * 0.008 / dt, 1),
            "unit": "x real time", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True, "dtype": "f32", "data": "synthetic",
-           "frames_per_s": round(streams / dt, 1),
+           "frames_per_s": round(streams / dt, 1), "hip_graph": graphed,
            "config": {"workload": "config/tiny.json TRU-Net eval forward, randn(1024,4,257) per step (rt.py protocol)"}}
     print(json.dumps(out), flush=True)
 
@@ -123,6 +142,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stft-loss", action="store_true", help="ablation (BASELINE.json configs[4])")
     ap.add_argument("--no-pcen", action="store_true", help="ablation (BASELINE.json configs[4])")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) and the gradient all-reduce even with one rank")
     ap.add_argument("--streaming", action="store_true",
                     help="BASELINE.json configs[3]: 1-frame causal forward of 1024 concurrent streams (rt.py protocol)")
     args = ap.parse_args()
@@ -134,9 +155,11 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from tinyrecurrentunet_amd import distributed as tdist, engine, network as hn, optim, stft_loss as sl, util
     if args.streaming:
@@ -144,7 +167,7 @@ def main():
     cin = 3 if args.no_pcen else 4
     torch.manual_seed(0)                      # train.py:12-14
     net = hn.TRUNet(input_size=cin).to(dev).train()
-    if world > 1:
+    if use_dist:
         tdist.apply_gradient_allreduce(net)
     opt = optim.FusedAdamW(net.parameters(), lr=4e-4)
     sched = util.LinearWarmupCosineDecay(opt, lr_max=4e-4, n_iter=25000000, iteration=0, divider=25,
@@ -169,7 +192,7 @@ def main():
         step()
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -179,7 +202,7 @@ def main():
         loss, nsq = step()
     sync()
     dt = time.time() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
@@ -236,12 +259,12 @@ def main():
                                           cin, " incl. PCEN" if cin == 4 else "", args.batch, args.seconds,
                                           "" if stft_lambda else " WITHOUT MR-STFT loss"),
                           "frames_per_gpu": frames, "global_batch": args.batch * world,
-                          "parallelism": "dp%d" % world, "loss": float(loss)},
+                          "parallelism": "dp%d" % world, "loss": float(loss.detach())},
                "roofline": roof, "cpu_baseline": cpu}
         if cpu:
             out["gpu_over_cpu"] = round(value / cpu["value"], 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
