@@ -120,6 +120,33 @@ typedef struct {
 int trunet_conv_wgrad_nparts(void);
 int trunet_conv_wgrad(const trunet_wgrad_args* h_args, void* stream);
 
+/* Fused backward of a Conv1d(k=1) layer in front of a BatchNorm (autograd of network.py:28,50,64,83 with the
+ * F.pad/torch.cat of :96-98): ONE pass over (dy, z, sources) yields the weight/bias gradient partial images of
+ * trunet_conv_wgrad AND, per source segment s, the data gradient
+ *   g_s[c][q_s(p)][n] = sum_m W[m][woff_s + c] * dz[m][p][n]  (+ previous content of out)  (* [e0*zmask + e1 > 0])
+ * with e0 = seg.c0, e1 = seg.c1 of the segment (1, 0 for TRUNET_PRO_NONE), plus the BatchNorm-backward statistics
+ * sum(g_s), sum(g_s * (zmask - e2)) of that source: partials[trunet_pw_bwd_nparts()][nchan][2].
+ * Restrictions (else TRUNET_ENOTSUP, use trunet_conv_gemm + trunet_conv_wgrad): w.a_mode = TRUNET_PRO_BNBWD,
+ * M in {32,64,96,128}, every segment pos_mul = pos_div = 1 and nchan % 32 == 0, sum nchan in {64,128,192}. */
+enum { TRUNET_DG_STORE = 1,  /* write the data gradient of this segment to `out`          */
+       TRUNET_DG_MASK = 2,   /* ReLU backward: multiply by [e0*zmask + e1 > 0]             */
+       TRUNET_DG_STATS = 4,  /* BatchNorm-backward statistics of the source (needs MASK)   */
+       TRUNET_DG_ACCUM = 8   /* add the value already stored in `out` before masking       */ };
+typedef struct {
+    float* out;            /* [nchan][seg.L][NP] */
+    const float* zmask;    /* raw tensor of the source, same shape */
+    const float* e2;       /* per-channel mean of the source's BatchNorm (STATS) */
+    float* partials;       /* [trunet_pw_bwd_nparts()][nchan][2], zero-filled by the call */
+    int32_t flags; int32_t _pad;
+} trunet_dgrad_out;
+typedef struct {
+    trunet_wgrad_args w;   /* weight-gradient half: same meaning as for trunet_conv_wgrad */
+    const float* W;        /* the layer's weight, addressed like w (ldw_m, ldw_c, w_m_off, seg.woff) */
+    trunet_dgrad_out dg[TRUNET_MAX_SEG];
+} trunet_pwbwd_args;
+int trunet_pw_bwd_nparts(void);
+int trunet_pw_bwd(const trunet_pwbwd_args* h_args, void* stream);
+
 /* out[i] (+)= sum_g partials[g][i]  (deterministic second stage of every split reduction) */
 int trunet_reduce_partials(float* out, const float* partials, int nparts, int numel, int accumulate,
                            void* stream);

@@ -26,6 +26,8 @@ def test_c_abi_exports_every_declared_symbol():
     assert ctypes.sizeof(_lib.Seg) == 5 * 8 + 8 * 4
     assert ctypes.sizeof(_lib.GemmArgs) == 14 * 4 + 8 * 8 + 5 * ctypes.sizeof(_lib.Seg)
     assert ctypes.sizeof(_lib.WgradArgs) == 16 * 4 + 7 * 8 + 2 * 4 + 5 * ctypes.sizeof(_lib.Seg)
+    assert ctypes.sizeof(_lib.DgradOut) == 4 * 8 + 2 * 4
+    assert ctypes.sizeof(_lib.PwBwdArgs) == ctypes.sizeof(_lib.WgradArgs) + 8 + 5 * ctypes.sizeof(_lib.DgradOut)
 
 
 def test_product_does_not_import_oracle():

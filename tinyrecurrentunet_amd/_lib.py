@@ -44,6 +44,17 @@ class WgradArgs(C.Structure):
                 ("seg", Seg * MAX_SEG)]
 
 
+DG_STORE, DG_MASK, DG_STATS, DG_ACCUM = 1, 2, 4, 8
+
+
+class DgradOut(C.Structure):
+    _fields_ = [("out", _fp), ("zmask", _fp), ("e2", _fp), ("partials", _fp), ("flags", C.c_int32), ("_pad", C.c_int32)]
+
+
+class PwBwdArgs(C.Structure):
+    _fields_ = [("w", WgradArgs), ("W", _fp), ("dg", DgradOut * MAX_SEG)]
+
+
 _lib = None
 
 
@@ -71,6 +82,8 @@ def _declare(L):
         "trunet_conv_gemm_plan": [C.POINTER(GemmArgs)] + [C.POINTER(C.c_int)] * 6,
         "trunet_conv_wgrad_nparts": [],
         "trunet_conv_wgrad": [C.POINTER(WgradArgs), p],
+        "trunet_pw_bwd_nparts": [],
+        "trunet_pw_bwd": [C.POINTER(PwBwdArgs), p],
         "trunet_reduce_partials": [p, p, i, i, i, p],
         "trunet_bn_finalize_fwd": [p, i, i, d, p, p, f, f, p, p, p, p, p, p, p],
         "trunet_bn_eval_affine": [i, p, p, p, p, f, p, p, p],

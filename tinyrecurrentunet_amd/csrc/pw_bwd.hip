@@ -1,0 +1,638 @@
+// Fused backward of a pointwise (k = 1) convolution layer:  y[m][p][n] = sum_s sum_c W[m][woff_s + c] a_s[c][q_s(p)][n] + b[m],
+// a_s = max(c0 z_s + c1, lo) (BatchNorm+ReLU of the source's raw tensor z_s, or the tensor itself).
+//
+// One pass over (dy, z_y, z_s) produces everything the layer's backward needs:
+//   dz         = ca dy + cb z_y + cc                          (BatchNorm backward of y, in LDS, never written)
+//   dW, db     = sum_{p,n} dz a_s^T , sum dz                   (per-workgroup partial images, as conv_wgrad)
+//   g_s        = W_s^T dz  [+ previous content] [masked by a_s > 0]   -> gradient w.r.t. the source's raw tensor
+//   statistics = sum g_s, sum g_s (z_s - mean_s)               (BatchNorm backward of the source)
+// The separate conv_gemm (data gradient) + conv_wgrad launches read dy and z_y twice and z_s twice; this kernel
+// reads each once (7 tensor passes -> 4), which is what bounds the layer at 128 channels (measured 3.7 TB/s in
+// both of the separate kernels).
+//
+// Tile = one position p x 32 frames of every operand row, delivered by LDS-DMA into a ring of NB slots exactly as
+// in conv_wgrad_kernel (rows of 128 B, 16-byte pieces XOR-swizzled through the per-lane SOURCE address; the
+// requesting thread applies the prologue in place; all 8 waves share DMA issue and prologue).  The MFMA work is
+// split by ROLE, one wave of each role per SIMD, so that the two register-hungry accumulator sets never meet in
+// one wave:
+//   * waves 0-3 (weight gradient): <= 4 output tiles (32x32) each in accumulators for the whole kernel; the frame
+//     axis is the MFMA K axis; a wave's tiles share the dz row tile, so its A fragments are read once.
+//   * waves 4-7 (data gradient): the rows of dz are the MFMA K axis.  A wave owns one 32-channel row tile of the
+//     sources for the whole kernel (plus, with six row tiles, a second one on alternate tiles), keeps the matching
+//     W^T fragments in registers, and runs the epilogue (accumulate / ReLU mask / statistics / store) itself.
+// The two roles execute different loops with the same barrier sequence.
+#include <type_traits>
+#include "common.hpp"
+
+namespace {
+
+constexpr int WFC = 32;          // frames per tile
+constexpr int PMAXT = 4;         // weight-gradient accumulator tiles per wave (waves 0-3)
+constexpr int PD = 2;            // dz DMA row groups per wave   (M <= 128)
+constexpr int PS = 3;            // source DMA row groups per wave (sum of channels <= 192)
+constexpr int PWB_GRID = TRUNET_NUM_CU;
+constexpr int PWB_SHARE = 2;     // partial statistics rows per workgroup
+
+// data-gradient schedule of waves 4..7 (index j = wave - 4): row tiles over the concatenated source channels
+struct PwbSched {
+    int8_t rt[4], period[4], phase[4], share[4];         // primary row tile: tiles t with (t & (period-1)) == phase
+    int8_t rt2[4], period2[4], phase2[4], share2[4];     // secondary row tile (-1: none)
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ void pwb_wait_vmcnt(int n) {
+    switch (n) {
+#define W_(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+        W_(0) W_(1) W_(2) W_(3) W_(4) W_(5) W_(6) W_(7) W_(8) W_(9) W_(10) W_(11) W_(12) W_(13) W_(14) W_(15)
+        W_(16) W_(17) W_(18) W_(19) W_(20) W_(21) W_(22) W_(23) W_(24) W_(25) W_(26) W_(27) W_(28) W_(29) W_(30) W_(31)
+        W_(32) W_(33) W_(34) W_(35) W_(36) W_(37) W_(38) W_(39) W_(40) W_(41) W_(42) W_(43) W_(44) W_(45) W_(46) W_(47)
+        W_(48) W_(49) W_(50) W_(51) W_(52) W_(53) W_(54) W_(55) W_(56) W_(57) W_(58) W_(59) W_(60)
+#undef W_
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+// swizzled float offset of 16-byte piece `pc` (0..7) of row `r` inside a slot
+__device__ __forceinline__ int pwb_off(int r, int pc) { return r * WFC + 4 * (pc ^ ((r >> 1) & 7)); }
+
+struct PSegPos { bool valid; int q; };
+__device__ __forceinline__ PSegPos pwb_seg_pos(const trunet_seg& sg, int p) {
+    const int q = p + sg.pos_off;
+    PSegPos r;
+    r.q = q;
+    r.valid = (q >= 0) && (q < sg.L);
+    return r;
+}
+
+// wave-uniform values the compiler cannot prove uniform (they pass through per-wave role tables)
+__device__ __forceinline__ int pwb_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ size_t pwb_uniform(size_t v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((size_t)hi << 32) | lo;
+}
+template <typename T>
+__device__ __forceinline__ T* pwb_uniform(T* p) { return (T*)pwb_uniform((size_t)p); }
+
+// one data-gradient row tile of a wave: what is fixed for the kernel ...
+struct DUnit {
+    int seg, ct, cb, flags, mask, phase, share;   // segment, 32-channel tile in it, coefficient base, TRUNET_DG_*
+};
+// ... and what changes with the position p
+struct DRun {
+    bool valid;
+    const float* zb;      // (channel 32*ct, position q, frame 0) of the source's raw tensor
+    float* ob;            // same element of the data-gradient output
+    size_t dstride;       // elements between consecutive channels
+    int voff;             // per-lane byte offset: 4h channels down, frame c
+};
+
+// AK: k-pairs of the data-gradient A fragments = padded dz rows / 2 (32 for M <= 64, 64 for M <= 128)
+// SEC: data-gradient waves carry a second row tile (six row tiles over four waves)
+template <int AK, bool SEC>
+__global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args A, const PwbSched sch, const int NB,
+                                                        const int rows) {
+    const trunet_wgrad_args& a = A.w;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int c = lane & 31;
+    constexpr int MA = 2 * AK;                // padded dz rows
+    constexpr int nrt = MA / 32;
+    constexpr int DZR = 2 * MA;               // rows of the dz block (dy, z)
+    constexpr int Gd = MA / 8;
+    const int Gs = (rows - DZR) / 8;
+    const int PPW = (Gd - wave + 7) / 8;      // this wave's dz row groups
+    const int SPW = (Gs - wave + 7) / 8;      // this wave's source row groups
+    const int LPW = PPW * 2 + SPW;            // this wave's DMA instructions per tile
+    const int SLOT = rows * WFC;              // floats per slot
+
+    float* R_lds = smem;
+    f32x4* CA = (f32x4*)(R_lds + (size_t)NB * SLOT);      // [MA] dz coefficients
+    f32x4* CB = CA + MA;                                     // [sum nchan] (c0, c1, lo, mean) of the sources
+
+    for (int r = tid; r < MA; r += 512) {
+        const int ch = min(r, a.M - 1) + a.a_m_off;
+        f32x4 k = {a.ac0[ch], a.ac1[ch], a.ac2[ch], 0.f};
+        if (r >= a.M) { k[0] = 0.f; k[1] = 0.f; k[2] = 0.f; }
+        CA[r] = k;
+    }
+    {
+        int base = 0;
+        for (int s = 0; s < a.nseg; ++s) {
+            const trunet_seg& sg = a.seg[s];
+            const trunet_dgrad_out& dg = A.dg[s];
+            for (int ci = tid; ci < sg.nchan; ci += 512) {
+                const bool on = sg.mode == TRUNET_PRO_BNRELU;
+                f32x4 k = {on ? sg.c0[ci] : 1.f, on ? sg.c1[ci] : 0.f, on ? 0.f : -3.0e38f,
+                           ((dg.flags & TRUNET_DG_STATS) && dg.e2) ? dg.e2[ci] : 0.f};
+                CB[base + ci] = k;
+            }
+            base += sg.nchan;
+        }
+    }
+    float bsum[PD];
+#pragma unroll
+    for (int i = 0; i < PD; ++i) bsum[i] = 0.f;
+
+    const int nfc = a.NP / WFC;
+    const int total_tiles = a.P * nfc;
+    const int t_begin = (int)(((long long)blockIdx.x * total_tiles) / gridDim.x);
+    const int t_end = (int)(((long long)(blockIdx.x + 1) * total_tiles) / gridDim.x);
+    __syncthreads();
+
+    // ---- the tile pipeline, shared by both roles: begin_run(p, sbase) once per run of tiles with equal p,
+    // compute(t, S, n0) between the prologue pass of tile t+1 and the barrier that releases tile t's slot
+    auto pipeline = [&](auto begin_run, auto compute) __attribute__((always_inline)) {
+        if (t_begin >= t_end) return;
+        const int pc = lane & 7;
+        int t0 = t_begin;
+        while (t0 < t_end) {
+            const int pi = t0 / nfc;
+            const int p = a.p_begin + pi;
+            const int t1 = min(t_end, (pi + 1) * nfc);       // tiles [t0, t1) share p; frame chunk = t - pi*nfc
+            // staged segment list: the valid segments in order, the last one repeated up to nseg entries
+            int sl[TRUNET_MAX_SEG], sq[TRUNET_MAX_SEG], sbase[TRUNET_MAX_SEG];
+            int nvalid = 0;
+            {
+                int lasts = 0, lastq = 0;
+#pragma unroll
+                for (int s = 0; s < TRUNET_MAX_SEG; ++s) { sl[s] = 0; sq[s] = 0; sbase[s] = -1; }
+#pragma unroll
+                for (int s = 0; s < TRUNET_MAX_SEG; ++s) {
+                    if (s < a.nseg) {
+                        const PSegPos sp = pwb_seg_pos(a.seg[s], p);
+                        if (sp.valid) {
+#pragma unroll
+                            for (int j = 0; j < TRUNET_MAX_SEG; ++j) if (j == nvalid) { sl[j] = s; sq[j] = sp.q; }
+                            lasts = s; lastq = sp.q; ++nvalid;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < TRUNET_MAX_SEG; ++j) if (j >= nvalid && j < a.nseg) { sl[j] = lasts; sq[j] = lastq; }
+                int rb = DZR;
+#pragma unroll
+                for (int j = 0; j < TRUNET_MAX_SEG; ++j) {
+                    if (j < nvalid) {
+#pragma unroll
+                        for (int s = 0; s < TRUNET_MAX_SEG; ++s) if (sl[j] == s) sbase[s] = rb;
+                    }
+                    if (j < a.nseg) rb += (a.seg[sl[j]].nchan + 31) & ~31;
+                }
+            }
+            // per-lane source pointers (frame 0 of this lane's row, logical piece folded in) and coefficient rows
+            const float* pd[PD];      // dy rows
+            const float* pzr[PD];     // z rows
+            const float* ps[PS];      // source rows
+            int cidx[PS];
+#pragma unroll
+            for (int i = 0; i < PD; ++i) {
+                pd[i] = a.a0; pzr[i] = a.a0;
+                if (i < PPW) {
+                    const int r = 8 * (wave + 8 * i) + (lane >> 3);
+                    const int lc = pc ^ ((r >> 1) & 7);
+                    const int m = min(r, a.M - 1) + a.a_m_off;
+                    const size_t off = ((size_t)m * a.a_L + p + a.a_pos_off) * a.NP + 4 * lc;
+                    pd[i] = a.a0 + off;
+                    pzr[i] = a.a1 + off;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < PS; ++i) {
+                ps[i] = a.a0; cidx[i] = 0;
+                if (i < SPW) {
+                    const int g = wave + 8 * i;
+                    int rb = 0, sidx = sl[0], q = sq[0], ch0 = 0;
+#pragma unroll
+                    for (int j = 0; j < TRUNET_MAX_SEG; ++j) {
+                        if (j < a.nseg) {
+                            const int srp = (a.seg[sl[j]].nchan + 31) & ~31;
+                            if (8 * g >= rb && 8 * g < rb + srp) { sidx = sl[j]; q = sq[j]; ch0 = 8 * g - rb; }
+                            rb += srp;
+                        }
+                    }
+                    const trunet_seg& sg = a.seg[sidx];
+                    const int r = DZR + 8 * g + (lane >> 3);
+                    const int lc = pc ^ ((r >> 1) & 7);
+                    const int ci = min(ch0 + (lane >> 3), sg.nchan - 1);
+                    ps[i] = sg.src0 + ((size_t)ci * sg.L + q) * a.NP + 4 * lc;
+                    int cb = 0;
+                    for (int s = 0; s < sidx; ++s) cb += a.seg[s].nchan;
+                    cidx[i] = cb + ci;
+                }
+            }
+            begin_run(p, sbase);
+
+            auto issue_dma = [&](int t, int slot) __attribute__((always_inline)) {
+                const int n0 = (t - pi * nfc) * WFC;
+                float* dst = R_lds + (size_t)slot * SLOT;
+#pragma unroll
+                for (int i = 0; i < PD; ++i) {
+                    if (i < PPW) {
+                        const int g = wave + 8 * i;
+                        __builtin_amdgcn_global_load_lds(pd[i] + n0, (lds_ptr_t)(dst + g * 256), 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds(pzr[i] + n0, (lds_ptr_t)(dst + (MA / 8 + g) * 256), 16, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < PS; ++i) {
+                    if (i < SPW) {
+                        const int g = wave + 8 * i;
+                        __builtin_amdgcn_global_load_lds(ps[i] + n0, (lds_ptr_t)(dst + (DZR / 8 + g) * 256), 16, 0, 0);
+                    }
+                }
+            };
+            // prologue pass on this thread's own pieces of tile t
+            auto transform = [&](int t, int slot) __attribute__((always_inline)) {
+                const int n0 = (t - pi * nfc) * WFC;
+                float* dst = R_lds + (size_t)slot * SLOT;
+#pragma unroll
+                for (int i = 0; i < PD; ++i) {
+                    if (i < PPW) {
+                        const int r = 8 * (wave + 8 * i) + (lane >> 3);
+                        const int lc = pc ^ ((r >> 1) & 7);
+                        float* pz = dst + r * WFC + 4 * pc;
+                        f32x4 v = *(f32x4*)pz;
+                        const f32x4 k = CA[r];
+                        const f32x4 z = *(const f32x4*)(pz + MA * WFC);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaf(k[0], v[e], fmaf(k[1], z[e], k[2]));
+                        float sacc = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (n0 + 4 * lc + e >= a.N) v[e] = 0.f;
+                            sacc += v[e];
+                        }
+                        bsum[i] += sacc;
+                        *(f32x4*)pz = v;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < PS; ++i) {
+                    if (i < SPW) {
+                        const f32x4 k = CB[cidx[i]];
+                        float* pz = dst + (DZR + 8 * (wave + 8 * i) + (lane >> 3)) * WFC + 4 * pc;
+                        f32x4 v = *(f32x4*)pz;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], k[0], k[1]), k[2]);
+                        *(f32x4*)pz = v;
+                    }
+                }
+            };
+
+            // ---- pipeline over tiles [t0, t1): NB tiles in flight, first one transformed
+            for (int d = 0; d < NB; ++d) issue_dma(min(t0 + d, t1 - 1), d);
+            pwb_wait_vmcnt((NB - 1) * LPW);
+            transform(t0, 0);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            int slot = 0;
+            for (int t = t0; t < t1; ++t) {
+                if (t + 1 < t1) {
+                    pwb_wait_vmcnt((NB - 2) * LPW);
+                    transform(t + 1, (slot + 1 == NB) ? 0 : slot + 1);
+                }
+                compute(t, R_lds + (size_t)slot * SLOT, pwb_uniform((t - pi * nfc) * WFC));
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                issue_dma(min(t + NB, t1 - 1), slot);        // refill the slot just released
+                slot = (slot + 1 == NB) ? 0 : slot + 1;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();                     // ring is reused by the next run of tiles
+            asm volatile("" ::: "memory");
+            t0 = t1;
+        }
+    };
+
+    if (wave < 4) {
+        // =================== weight-gradient role: tiles g = wave + 4 i -> (row tile g % nrt = wave % nrt, k tile g / nrt)
+        const int my_rt = wave % nrt;
+        int t_seg[PMAXT], t_ct[PMAXT];
+#pragma unroll
+        for (int i = 0; i < PMAXT; ++i) {
+            int kt = (wave + 4 * i) / nrt;
+            t_seg[i] = -1; t_ct[i] = 0;
+#pragma unroll
+            for (int s = 0; s < TRUNET_MAX_SEG; ++s) {
+                if (s < a.nseg && t_seg[i] < 0 && kt >= 0) {
+                    const int nt = (a.seg[s].nchan + 31) / 32;
+                    if (kt < nt) { t_seg[i] = s; t_ct[i] = kt; }
+                    else kt -= nt;
+                }
+            }
+        }
+        f32x16 acc[PMAXT];
+#pragma unroll
+        for (int i = 0; i < PMAXT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        int rb_run[PMAXT];       // first LDS row of tile i's source rows in this run, -1: segment not valid at p
+        pipeline(
+            [&](int, const int* sbase) __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < PMAXT; ++i) {
+                    int sb = -1;
+#pragma unroll
+                    for (int s = 0; s < TRUNET_MAX_SEG; ++s) if (t_seg[i] == s) sb = sbase[s];
+                    rb_run[i] = sb >= 0 ? sb + t_ct[i] * 32 : -1;
+                }
+            },
+            [&](int, const float* S, int) __attribute__((always_inline)) {
+                const int ra = my_rt * 32 + c;
+#pragma unroll
+                for (int q = 0; q < WFC / 8; ++q) {
+                    const f32x4 av = *(const f32x4*)(S + pwb_off(ra, 2 * q + h));
+#pragma unroll
+                    for (int i = 0; i < PMAXT; ++i) {
+                        if (rb_run[i] >= 0) {
+                            const f32x4 bv = *(const f32x4*)(S + pwb_off(rb_run[i] + c, 2 * q + h));
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[i], 0, 0, 0);
+                        }
+                    }
+                }
+            });
+        // this workgroup's partial image of dW
+        float* img = a.w_partials + (size_t)blockIdx.x * a.w_numel;
+#pragma unroll
+        for (int i = 0; i < PMAXT; ++i) {
+            if (t_seg[i] >= 0) {
+                const trunet_seg& sg = a.seg[t_seg[i]];
+                const int ci = t_ct[i] * 32 + c;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = my_rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (m < a.M && ci < sg.nchan)
+                        img[(size_t)(m + a.w_m_off) * a.ldw_m + (size_t)ci * a.ldw_c + sg.woff] = acc[i][r];
+                }
+            }
+        }
+    } else {
+        // =================== data-gradient role
+        const int j = wave - 4;
+        auto make_unit = [&](int rt, int period, int phase, int share) __attribute__((always_inline)) {
+            DUnit u;
+            u.seg = -1; u.ct = 0; u.cb = 0; u.flags = 0; u.mask = period - 1; u.phase = phase; u.share = share;
+            int g = rt, cb = 0;
+#pragma unroll
+            for (int s = 0; s < TRUNET_MAX_SEG; ++s) {
+                if (s < a.nseg && g >= 0 && u.seg < 0) {
+                    const int nt = (a.seg[s].nchan + 31) / 32;
+                    if (g < nt) { u.seg = s; u.ct = g; u.cb = cb; }
+                    else { g -= nt; cb += a.seg[s].nchan; }
+                }
+            }
+            if (u.seg >= 0) u.flags = A.dg[u.seg].flags;
+            u.seg = pwb_uniform(u.seg); u.ct = pwb_uniform(u.ct); u.cb = pwb_uniform(u.cb); u.flags = pwb_uniform(u.flags);
+            return u;
+        };
+        auto load_af = [&](const DUnit& u, float (&af)[AK]) {
+            const trunet_seg& sg = a.seg[max(u.seg, 0)];
+            const int ch = 32 * u.ct + c;
+            const bool chok = u.seg >= 0 && ch < sg.nchan;
+            const float* wp = A.W + (size_t)a.w_m_off * a.ldw_m + (size_t)min(ch, sg.nchan - 1) * a.ldw_c + sg.woff;
+#pragma unroll
+            for (int kk = 0; kk < AK; ++kk) {
+                const int m = 2 * kk + h;
+                const float v = wp[(size_t)min(m, a.M - 1) * a.ldw_m];     // all loads first, then the selects
+                af[kk] = (chok && m < a.M) ? v : 0.f;
+            }
+        };
+        auto begin_unit = [&](const DUnit& u, int p) __attribute__((always_inline)) {
+            DRun r;
+            r.valid = false; r.zb = nullptr; r.ob = nullptr; r.dstride = 0; r.voff = 0;
+            if (u.seg >= 0 && (u.flags & TRUNET_DG_STORE)) {
+                const trunet_seg& sg = a.seg[u.seg];
+                const PSegPos sp = pwb_seg_pos(sg, p);
+                r.valid = sp.valid;
+                r.dstride = pwb_uniform((size_t)sg.L * a.NP);
+                const size_t o = ((size_t)(32 * u.ct) * sg.L + (sp.valid ? sp.q : 0)) * a.NP;
+                r.zb = pwb_uniform(A.dg[u.seg].zmask + o);
+                r.ob = pwb_uniform(A.dg[u.seg].out + o);
+                r.voff = (int)((4 * h * r.dstride + c) * sizeof(float));
+            }
+            return r;
+        };
+        // one row tile of one tile: MFMAs over the dz rows, then the epilogue; FL = the segment's TRUNET_DG_* flags
+        auto dgrad = [&](auto FLc, const DUnit& u, const DRun& dr, const float (&af)[AK], float (&st1)[16],
+                         float (&st2)[16], const float* S, int n0) __attribute__((always_inline)) {
+            constexpr int FL = decltype(FLc)::value;
+            const float* zb = pwb_uniform(dr.zb);
+            float* ob = pwb_uniform(dr.ob);
+            const size_t dstride = pwb_uniform(dr.dstride);
+            // epilogue operands: hand-issued (uniform row base + per-lane offset keeps 64-bit addresses out of the
+            // VGPR budget, and the compiler would drain the DMA ring at their first use); waited for after the MFMAs
+            float zv[16], ov[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { zv[r] = 0.f; ov[r] = 0.f; }
+            if (FL & TRUNET_DG_MASK) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float* rp = zb + (size_t)((r & 3) + 8 * (r >> 2)) * dstride + n0;
+                    asm volatile("global_load_dword %0, %1, %2" : "=v"(zv[r]) : "v"(dr.voff), "s"(rp) : "memory");
+                }
+            }
+            if (FL & TRUNET_DG_ACCUM) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float* rp = ob + (size_t)((r & 3) + 8 * (r >> 2)) * dstride + n0;
+                    asm volatile("global_load_dword %0, %1, %2" : "=v"(ov[r]) : "v"(dr.voff), "s"(rp) : "memory");
+                }
+            }
+            f32x16 dacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dacc[r] = 0.f;
+            const float* Sb = S + h * WFC + (c & 3);
+            const int cpc = c >> 2;
+#pragma unroll
+            for (int kk = 0; kk < AK; ++kk) {
+                const float b = Sb[kk * (2 * WFC) + 4 * (cpc ^ (kk & 7))];
+                dacc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], b, dacc, 0, 0, 0);
+            }
+            // The stores below are inline asm: the compiler's hazard recogniser does not pad between the last MFMA
+            // (16 passes) and an asm instruction that reads its result, so wait it out here (>= 19 wait states).
+            asm volatile("s_nop 15\n\ts_nop 7" : "+v"(dacc) :: "memory");
+            // the loaded values become visible to the compiler only through these two statements
+            if (FL & (TRUNET_DG_MASK | TRUNET_DG_ACCUM)) {
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(zv[0]), "+v"(zv[1]), "+v"(zv[2]), "+v"(zv[3]), "+v"(zv[4]), "+v"(zv[5]), "+v"(zv[6]),
+                               "+v"(zv[7]), "+v"(zv[8]), "+v"(zv[9]), "+v"(zv[10]), "+v"(zv[11]), "+v"(zv[12]),
+                               "+v"(zv[13]), "+v"(zv[14]), "+v"(zv[15]) :: "memory");
+                asm volatile(""
+                             : "+v"(ov[0]), "+v"(ov[1]), "+v"(ov[2]), "+v"(ov[3]), "+v"(ov[4]), "+v"(ov[5]), "+v"(ov[6]),
+                               "+v"(ov[7]), "+v"(ov[8]), "+v"(ov[9]), "+v"(ov[10]), "+v"(ov[11]), "+v"(ov[12]),
+                               "+v"(ov[13]), "+v"(ov[14]), "+v"(ov[15]) :: "memory");
+            }
+            const f32x4* CBs = CB + u.cb + 32 * u.ct + 4 * h;
+            const bool fin = n0 + c < a.N;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = (r & 3) + 8 * (r >> 2);
+                if ((r & 3) == 0) asm volatile("" ::: "memory");   // coefficient reads: four rows at a time
+                float val = dacc[r];
+                if (FL & TRUNET_DG_ACCUM) val += ov[r];
+                f32x4 k = {0.f, 0.f, 0.f, 0.f};
+                if (FL & TRUNET_DG_MASK) {
+                    k = CBs[ml];
+                    val = (fmaf(k[0], zv[r], k[1]) > 0.f) ? val : 0.f;
+                }
+                float* rp = ob + (size_t)ml * dstride + n0;
+                asm volatile("global_store_dword %0, %1, %2" :: "v"(dr.voff), "v"(val), "s"(rp) : "memory");
+                if (FL & TRUNET_DG_STATS) {
+                    const float x = fin ? val : 0.f;
+                    st1[r] += x;
+                    st2[r] = fmaf(x, zv[r] - k[3], st2[r]);
+                }
+            }
+        };
+        auto dgrad_any = [&](const DUnit& u, const DRun& dr, const float (&af)[AK], float (&st1)[16], float (&st2)[16],
+                             int t, const float* S, int n0) __attribute__((always_inline)) {
+            if (!dr.valid || ((t & u.mask) != u.phase)) return;
+            constexpr int S_ = TRUNET_DG_STORE, M_ = TRUNET_DG_MASK, T_ = TRUNET_DG_STATS, C_ = TRUNET_DG_ACCUM;
+            if (u.flags == S_) dgrad(std::integral_constant<int, S_>(), u, dr, af, st1, st2, S, n0);
+            else if (u.flags == (S_ | M_ | T_)) dgrad(std::integral_constant<int, S_ | M_ | T_>(), u, dr, af, st1, st2, S, n0);
+            else if (u.flags == (S_ | M_ | T_ | C_)) dgrad(std::integral_constant<int, S_ | M_ | T_ | C_>(), u, dr, af, st1, st2, S, n0);
+            else dgrad(std::integral_constant<int, S_ | M_ | C_>(), u, dr, af, st1, st2, S, n0);
+        };
+        auto write_stats = [&](const DUnit& u, const float (&st1)[16], const float (&st2)[16]) {
+            if (u.seg < 0 || !(u.flags & TRUNET_DG_STATS)) return;
+            const trunet_dgrad_out& dg = A.dg[u.seg];
+            const int nch = a.seg[u.seg].nchan;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float s1 = half_wave_sum(st1[r]);
+                const float s2 = half_wave_sum(st2[r]);
+                const int ch = 32 * u.ct + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (c == 0 && ch < nch) {
+                    float* pp = dg.partials + ((size_t)(blockIdx.x * PWB_SHARE + u.share) * nch + ch) * 2;
+                    pp[0] = s1;
+                    pp[1] = s2;
+                }
+            }
+        };
+
+        const DUnit u1 = make_unit(sch.rt[j], sch.period[j], sch.phase[j], sch.share[j]);
+        const DUnit u2 = make_unit(SEC ? sch.rt2[j] : -1, sch.period2[j], sch.phase2[j], sch.share2[j]);
+        float af1[AK], af2[SEC ? AK : 1];
+        float sa1[16], sa2[16], sb1[SEC ? 16 : 1], sb2[SEC ? 16 : 1];
+        load_af(u1, af1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sa1[r] = 0.f; sa2[r] = 0.f; }
+        if constexpr (SEC) {
+            load_af(u2, af2);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sb1[r] = 0.f; sb2[r] = 0.f; }
+        }
+        DRun r1, r2;
+        pipeline(
+            [&](int p, const int*) __attribute__((always_inline)) {
+                r1 = begin_unit(u1, p);
+                if constexpr (SEC) r2 = begin_unit(u2, p);
+            },
+            [&](int t, const float* S, int n0) __attribute__((always_inline)) {
+                dgrad_any(u1, r1, af1, sa1, sa2, t, S, n0);
+                if constexpr (SEC) dgrad_any(u2, r2, af2, sb1, sb2, t, S, n0);
+            });
+        write_stats(u1, sa1, sa2);
+        if constexpr (SEC) write_stats(u2, sb1, sb2);
+    }
+
+    if (a.b_partials) {
+#pragma unroll
+        for (int i = 0; i < PD; ++i) {
+            float v = bsum[i];
+            v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 1);
+            const int row = 8 * (wave + 8 * i) + (lane >> 3);
+            if ((lane & 7) == 0 && i < PPW && row < a.M)
+                a.b_partials[(size_t)blockIdx.x * a.b_stride + a.b_off + row] = v;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int trunet_pw_bwd_nparts(void) { return PWB_GRID * PWB_SHARE; }
+
+extern "C" int trunet_pw_bwd(const trunet_pwbwd_args* H, void* stream) {
+    if (!H || !H->W) return TRUNET_EINVAL;
+    const trunet_wgrad_args* h = &H->w;
+    if (!h->a0 || !h->a1 || !h->w_partials || h->nseg < 1 || h->nseg > TRUNET_MAX_SEG) return TRUNET_EINVAL;
+    if (h->NP <= 0 || (h->NP % TRUNET_TILE_FRAMES) != 0 || h->N > h->NP || h->P <= 0 || h->M <= 0) return TRUNET_EINVAL;
+    if (h->a_mode != TRUNET_PRO_BNBWD || !h->ac0 || !h->ac1 || !h->ac2) return TRUNET_ENOTSUP;
+    if (h->M > 128 || (h->M % 32) != 0) return TRUNET_ENOTSUP;
+    const int MA = h->M <= 64 ? 64 : 128;
+    int ktiles = 0, ntot = 0;
+    hipStream_t st = (hipStream_t)stream;
+    for (int s = 0; s < h->nseg; ++s) {
+        const trunet_seg& sg = h->seg[s];
+        const trunet_dgrad_out& dg = H->dg[s];
+        if (!sg.src0 || sg.nchan <= 0 || (sg.nchan % 32) != 0) return TRUNET_ENOTSUP;
+        if (sg.pos_mul != 1 || sg.pos_div != 1) return TRUNET_ENOTSUP;
+        if (sg.mode == TRUNET_PRO_BNBWD) return TRUNET_ENOTSUP;
+        if (sg.mode == TRUNET_PRO_BNRELU && (!sg.c0 || !sg.c1)) return TRUNET_EINVAL;
+        if (!(dg.flags & TRUNET_DG_STORE) || !dg.out) return TRUNET_ENOTSUP;
+        if ((dg.flags & TRUNET_DG_MASK) && !dg.zmask) return TRUNET_EINVAL;
+        if ((dg.flags & TRUNET_DG_STATS) && (!(dg.flags & TRUNET_DG_MASK) || !dg.partials)) return TRUNET_EINVAL;
+        if ((dg.flags & TRUNET_DG_ACCUM) && !(dg.flags & TRUNET_DG_MASK)) return TRUNET_ENOTSUP;
+        ktiles += sg.nchan / 32;
+        ntot += sg.nchan;
+    }
+    if (ktiles * (MA / 32) > 4 * PMAXT || ntot > 8 * 8 * PS) return TRUNET_ENOTSUP;
+    PwbSched sch;
+    for (int j = 0; j < 4; ++j) {
+        sch.rt[j] = -1; sch.period[j] = 1; sch.phase[j] = 0; sch.share[j] = 0;
+        sch.rt2[j] = -1; sch.period2[j] = 1; sch.phase2[j] = 0; sch.share2[j] = 0;
+    }
+    bool sec = false;
+    if (ktiles == 2) {          // two waves per row tile, alternating tiles
+        for (int j = 0; j < 4; ++j) { sch.rt[j] = j & 1; sch.period[j] = 2; sch.phase[j] = j >> 1; sch.share[j] = j >> 1; }
+    } else if (ktiles == 4) {   // one row tile per wave, every tile
+        for (int j = 0; j < 4; ++j) sch.rt[j] = j;
+    } else if (ktiles == 6) {   // row tiles 0-3 as above; 4, 5 by waves (0,1) on even and (2,3) on odd tiles
+        if (MA != 64) return TRUNET_ENOTSUP;
+        sec = true;
+        for (int j = 0; j < 4; ++j) {
+            sch.rt[j] = j;
+            sch.rt2[j] = 4 + (j & 1); sch.period2[j] = 2; sch.phase2[j] = j >> 1; sch.share2[j] = j >> 1;
+        }
+    } else {
+        return TRUNET_ENOTSUP;
+    }
+    const int rows = 2 * MA + ntot;
+    const size_t slot = (size_t)rows * WFC * sizeof(float);
+    const size_t fixed = (size_t)(MA + ntot) * sizeof(f32x4);
+    int NB = (int)((160 * 1024 - fixed) / slot);
+    if (NB > 4) NB = 4;
+    if (NB < 2) return TRUNET_ENOTSUP;
+    const size_t lds = fixed + NB * slot;
+    for (int s = 0; s < h->nseg; ++s) {
+        const trunet_dgrad_out& dg = H->dg[s];
+        if (dg.flags & TRUNET_DG_STATS) {
+            const size_t bytes = (size_t)PWB_GRID * PWB_SHARE * h->seg[s].nchan * 2 * sizeof(float);
+            if (hipMemsetAsync(dg.partials, 0, bytes, st) != hipSuccess) return TRUNET_ELAUNCH;
+        }
+    }
+#define PWB_LAUNCH(AK_, SEC_)                                                                                          \
+    do {                                                                                                               \
+        auto kern = pw_bwd_kernel<AK_, SEC_>;                                                                          \
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+            return TRUNET_ELAUNCH;                                                                                     \
+        hipLaunchKernelGGL(kern, dim3(PWB_GRID), dim3(512), lds, st, *H, sch, NB, rows);                               \
+    } while (0)
+    if (MA == 64 && sec) PWB_LAUNCH(32, true);
+    else if (MA == 64) PWB_LAUNCH(32, false);
+    else PWB_LAUNCH(64, false);
+#undef PWB_LAUNCH
+    return trunet_launch_status();
+}

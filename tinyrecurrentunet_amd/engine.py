@@ -13,14 +13,20 @@ PyTorch is used for device memory only; all arithmetic is in libtrunet_hip.so.
 import torch
 
 from . import _lib as L
-from ._lib import (EPI_ACCUM, EPI_BIAS, EPI_MASK, EPI_STATS, PRO_BNBWD, PRO_BNRELU, PRO_NONE, GemmArgs,
-                   WgradArgs, check, make_seg, ptr)
+import os
+
+from ._lib import (DG_ACCUM, DG_MASK, DG_STATS, DG_STORE, EPI_ACCUM, EPI_BIAS, EPI_MASK, EPI_STATS, PRO_BNBWD,
+                   PRO_BNRELU, PRO_NONE, GemmArgs, PwBwdArgs, WgradArgs, check, make_seg, ptr)
 
 F_BINS = 257
 FRAME_PAD = 256      # frames are padded to a multiple of 256 (widest conv_gemm tile)
 BN_EPS = 1e-5
 BN_MOM = 0.1
 
+
+# Backward of the pointwise convs in front of a BatchNorm: one fused launch (trunet_pw_bwd) instead of
+# trunet_conv_wgrad + trunet_conv_gemm; TRUNET_FUSED_PWBWD=0 keeps the separate launches (A/B measurements).
+FUSED_PWBWD = os.environ.get("TRUNET_FUSED_PWBWD", "1") != "0"
 
 # bench.py sets this to a dict to time kernels with HIP events on the launch stream:
 # PROFILE[kernel] = [(start_event, end_event, algorithmic_flops), ...]
@@ -454,6 +460,64 @@ class TRUNetEngine:
             return gw, gb
         return None
 
+    def _pw_bwd(self, w, *, N, NP, P, M, dz, dz1, dz_bn, W, bias, segs, outs, grads):
+        """Fused backward of a Conv1d(k=1)+BatchNorm layer (trunet_pw_bwd): weight/bias gradient and, per source
+        segment, the data gradient with its ReLU mask / skip accumulation / BatchNorm-backward statistics.
+        outs[i] = dict(out=tensor, src=Act or None (mask + statistics of that source), accum=bool)."""
+        lib = L.lib()
+        a = PwBwdArgs()
+        aw = a.w
+        numel = W.numel()
+        K = sum(s.nchan for s in segs)
+        aw.NP, aw.N, aw.P, aw.p_begin = NP, N, P, 0
+        aw.M, aw.a_L, aw.a_pos_off, aw.a_m_off = M, P, 0, 0
+        aw.ldw_m, aw.ldw_c, aw.w_m_off = K, 1, 0
+        aw.nseg = len(segs)
+        aw.w_numel = numel
+        aw.a0, aw.a1 = ptr(dz), ptr(dz1)
+        aw.a_mode = PRO_BNBWD
+        aw.ac0, aw.ac1, aw.ac2 = ptr(dz_bn.ca), ptr(dz_bn.cb), ptr(dz_bn.cc)
+        npw = lib.trunet_conv_wgrad_nparts()
+        wp = w.flat("w_partials", npw * 32768)
+        bp = w.flat("b_partials", npw * 512)
+        aw.w_partials, aw.b_partials = ptr(wp), ptr(bp)
+        aw.b_stride, aw.b_off = M, 0
+        a.W = ptr(W.data)
+        nparts = lib.trunet_pw_bwd_nparts()
+        stat_parts = []
+        for i, (sg, o) in enumerate(zip(segs, outs)):
+            aw.seg[i] = sg
+            d = a.dg[i]
+            d.out = ptr(o["out"])
+            fl = DG_STORE
+            src = o.get("src")
+            if src is not None:
+                fl |= DG_MASK
+                d.zmask = ptr(src.t)
+                if src.bn is not None:
+                    fl |= DG_STATS
+                    part = w.flat("pwb_partials%d" % i, nparts * sg.nchan * 2)
+                    d.e2, d.partials = ptr(src.bn.mean), ptr(part)
+                    stat_parts.append((src.bn, "pwb_partials%d" % i))
+                if o.get("accum"):
+                    fl |= DG_ACCUM
+            d.flags = fl
+        if PROFILE is not None:
+            fl_ = 4.0 * N * M * sum(s.nchan * _seg_positions(s, 0, P) for s in segs)
+            name = "pw_bwd_kernel<%d, %s>" % (32 if M <= 64 else 64, "true" if K == 192 else "false")
+            with _Timed(name, fl_, "M%d K%s P%d" % (M, "+".join(str(s.nchan) for s in segs), P)):
+                check(lib.trunet_pw_bwd(a, L.stream()), "pw_bwd")
+        else:
+            check(lib.trunet_pw_bwd(a, L.stream()), "pw_bwd")
+        gw = torch.empty_like(W)
+        gb = torch.empty(M, device=W.device, dtype=torch.float32)
+        check(lib.trunet_reduce_partials(ptr(gw), ptr(wp), npw, numel, 0, L.stream()), "reduce")
+        check(lib.trunet_reduce_partials(ptr(gb), ptr(bp), npw, M, 0, L.stream()), "reduce")
+        grads[W] = gw
+        grads[bias] = gb
+        for bn, pname in stat_parts:
+            self._bn_bwd(w, bn, nparts, grads, part_name=pname)
+
     def backward(self, ctx, gout):
         """gout: (N, 8, 257) cotangent.  Returns {parameter tensor: gradient}."""
         acts, N, NP, w = ctx
@@ -506,19 +570,25 @@ class TRUNetEngine:
                 skip, left = None, 0
                 srcs = [x1.seg()]
             Lp = a_pw.L
-            self._wgrad(w, N=N, NP=NP, P=Lp, M=pw.out_channels, dz=dy, dz1=z, dz_L=Lp, dz_bn=bn, W=pw.weight,
-                        ldw_m=Kin, ldw_c=1, segs=srcs, grads=grads, bias=pw.bias)
-            # data gradient, x1 part -> dy of x1's BN
             p0, p1 = max(0, left), min(Lp, x1.L + left)
             dy_x1 = w.get("dy:" + ("dec%d" % (i - 1) if i > 0 else "fgru"), (x1.C, x1.L, NP),
                           zero=(p1 - p0 < x1.L))
+            g_skip = w.get("dy:enc%d" % (5 - i), (skip.C, skip.L, NP)) if skip is not None else None
+            if FUSED_PWBWD and pw.out_channels % 32 == 0:
+                outs = [dict(out=dy_x1, src=x1)] + ([dict(out=g_skip)] if skip is not None else [])
+                self._pw_bwd(w, N=N, NP=NP, P=Lp, M=pw.out_channels, dz=dy, dz1=z, dz_bn=bn, W=pw.weight,
+                             bias=pw.bias, segs=srcs, outs=outs, grads=grads)
+                dy, z, bn = dy_x1, x1.t, x1.bn
+                continue
+            self._wgrad(w, N=N, NP=NP, P=Lp, M=pw.out_channels, dz=dy, dz1=z, dz_L=Lp, dz_bn=bn, W=pw.weight,
+                        ldw_m=Kin, ldw_c=1, segs=srcs, grads=grads, bias=pw.bias)
+            # data gradient, x1 part -> dy of x1's BN
             nparts = self._gemm(w, N=N, NP=NP, P=p1 - p0, p_begin=p0, M=x1.C, out=dy_x1, out_L=x1.L,
                                 out_pos_off=-left, W=pw.weight.data, ldw_m=1, ldw_c=Kin,
                                 segs=[dz_segs(dy, z, bn, pw.out_channels, Lp)], zmask=x1.t, e0=x1.bn.scale,
                                 e1=x1.bn.shift, e2=x1.bn.mean, stats=x1.C)
             self._bn_bwd(w, x1.bn, nparts, grads)
             if skip is not None:   # raw (unmasked) gradient w.r.t. the skip activation
-                g_skip = w.get("dy:enc%d" % (5 - i), (skip.C, skip.L, NP))
                 self._gemm(w, N=N, NP=NP, P=Lp, M=skip.C, out=g_skip, out_L=skip.L, W=pw.weight.data, ldw_m=1,
                            ldw_c=Kin, w_m_off=x1.C, segs=[dz_segs(dy, z, bn, pw.out_channels, Lp)])
             dy, z, bn = dy_x1, x1.t, x1.bn
@@ -528,11 +598,15 @@ class TRUNetEngine:
         hout = acts["hout"]
         gru = net.FGRU.GRU
         Hh, Lg = gru.hidden_size, hout.L
-        self._wgrad(w, N=N, NP=NP, P=Lg, M=conv.out_channels, dz=dy, dz1=z, dz_L=Lg, dz_bn=bn, W=conv.weight,
-                    ldw_m=conv.in_channels, ldw_c=1, segs=[hout.seg()], grads=grads, bias=conv.bias)
         dhout = w.get("dhout", (2 * Hh, Lg, NP))
-        self._gemm(w, N=N, NP=NP, P=Lg, M=2 * Hh, out=dhout, out_L=Lg, W=conv.weight.data, ldw_m=1,
-                   ldw_c=conv.in_channels, segs=[dz_segs(dy, z, bn, conv.out_channels, Lg)])
+        if FUSED_PWBWD:
+            self._pw_bwd(w, N=N, NP=NP, P=Lg, M=conv.out_channels, dz=dy, dz1=z, dz_bn=bn, W=conv.weight,
+                         bias=conv.bias, segs=[hout.seg()], outs=[dict(out=dhout)], grads=grads)
+        else:
+            self._wgrad(w, N=N, NP=NP, P=Lg, M=conv.out_channels, dz=dy, dz1=z, dz_L=Lg, dz_bn=bn, W=conv.weight,
+                        ldw_m=conv.in_channels, ldw_c=1, segs=[hout.seg()], grads=grads, bias=conv.bias)
+            self._gemm(w, N=N, NP=NP, P=Lg, M=2 * Hh, out=dhout, out_L=Lg, W=conv.weight.data, ldw_m=1,
+                       ldw_c=conv.in_channels, segs=[dz_segs(dy, z, bn, conv.out_channels, Lg)])
         # -------- GRU recurrence backward
         dgi = w.get("dgi", (6 * Hh, Lg, NP))
         dghn = w.get("dghn", (2 * Hh, Lg, NP))
@@ -605,11 +679,17 @@ class TRUNetEngine:
             dy, z, bn = dy_pw, a_pw.t, a_pw.bn
             prev = acts["enc%d" % (i - 1)]
             Lp = a_pw.L
-            self._wgrad(w, N=N, NP=NP, P=Lp, M=pw.out_channels, dz=dy, dz1=z, dz_L=Lp, dz_bn=bn, W=pw.weight,
-                        ldw_m=pw.in_channels, ldw_c=1, segs=[prev.seg()], grads=grads, bias=pw.bias)
             # data gradient -> dy of prev (accumulating the decoder's skip gradient already stored there)
             dy_prev = w.get("dy:enc%d" % (i - 1), (prev.C, prev.L, NP))
             has_skip = (i - 1) <= 4
+            if FUSED_PWBWD and has_skip:
+                self._pw_bwd(w, N=N, NP=NP, P=Lp, M=pw.out_channels, dz=dy, dz1=z, dz_bn=bn, W=pw.weight,
+                             bias=pw.bias, segs=[prev.seg()], outs=[dict(out=dy_prev, src=prev, accum=True)],
+                             grads=grads)
+                dy, z, bn = (dy_prev, prev.t, prev.bn) if prev.bn is not None else (dy_prev, None, None)
+                continue
+            self._wgrad(w, N=N, NP=NP, P=Lp, M=pw.out_channels, dz=dy, dz1=z, dz_L=Lp, dz_bn=bn, W=pw.weight,
+                        ldw_m=pw.in_channels, ldw_c=1, segs=[prev.seg()], grads=grads, bias=pw.bias)
             if prev.bn is not None:
                 nparts = self._gemm(w, N=N, NP=NP, P=Lp, M=prev.C, out=dy_prev, out_L=prev.L, W=pw.weight.data,
                                     ldw_m=1, ldw_c=pw.in_channels, segs=[dz_segs(dy, z, bn, pw.out_channels, Lp)],
