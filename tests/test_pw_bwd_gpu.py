@@ -202,3 +202,92 @@ def test_fgru_conv_raw_source():
 
 def test_first_decoder_pw_single_bn_source():
     _run_case(700, 3, 64, [(64, 3, "bn")])
+
+
+def _thin_wgrad_case(N, P, M, two, segspec):
+    """trunet_conv_wgrad on the thin shapes (vector-ALU kernel) vs a torch fp64 restatement.
+    segspec: list of (nchan, L, pos_mul, pos_off, pos_div, bn, shared_src_index or None)."""
+    from tinyrecurrentunet_amd import _lib as L
+    from tinyrecurrentunet_amd._lib import PRO_BNBWD, PRO_BNRELU, PRO_NONE, WgradArgs, check, make_seg, ptr
+    lib, st, dev = L.lib(), L.stream(), "cuda"
+    g = torch.Generator(device=dev)
+    g.manual_seed(7 * M + P + N)
+    rnd = lambda *s: torch.randn(*s, generator=g, device=dev)
+    NP = (N + 255) // 256 * 256
+    dy, z = rnd(M, P, NP), rnd(M, P, NP)
+    ca, cb, cc = rnd(M) * 0.5 + 1, rnd(M) * 0.1, rnd(M) * 0.01
+    srcs, segs, woff, info = {}, [], 0, []
+    nseg = len(segspec)
+    taps = all(s[6] is not None for s in segspec)
+    for i, (C, Ls, pm, po, pdv, bn, share) in enumerate(segspec):
+        key = share if share is not None else ("own", i)
+        if key not in srcs:
+            srcs[key] = (rnd(C, Ls, NP), rnd(C) * 0.3 + 1, rnd(C) * 0.2)
+        t, sc, sh = srcs[key]
+        wo = i if taps else woff
+        segs.append(make_seg(t, C, Ls, pos_mul=pm, pos_off=po, pos_div=pdv, woff=wo,
+                             mode=PRO_BNRELU if bn else PRO_NONE, c0=sc if bn else None, c1=sh if bn else None))
+        info.append((t, sc, sh, C, Ls, pm, po, pdv, bn, wo))
+        woff += C
+    Ktot = woff
+    # weight layouts: taps -> (M, C, k) conv style [ldw_m = C*k, ldw_c = k, woff = tap]; concat -> (M, Ktot)
+    C0 = segspec[0][0]
+    numel = M * (C0 * nseg if taps else Ktot)
+    a = WgradArgs()
+    a.NP, a.N, a.P, a.p_begin = NP, N, P, 0
+    a.M, a.a_L, a.a_pos_off, a.a_m_off = M, P, 0, 0
+    a.ldw_m, a.ldw_c = (C0 * nseg, nseg) if taps else (Ktot, 1)
+    a.w_m_off, a.nseg, a.w_numel = 0, nseg, numel
+    for i, sg in enumerate(segs):
+        a.seg[i] = sg
+    a.a0 = ptr(dy)
+    if two:
+        a.a1, a.a_mode, a.ac0, a.ac1, a.ac2 = ptr(z), PRO_BNBWD, ptr(ca), ptr(cb), ptr(cc)
+    else:
+        a.a_mode = PRO_NONE
+    npw = lib.trunet_conv_wgrad_nparts()
+    wp = torch.full((npw * numel,), float("nan"), device=dev)
+    bp = torch.full((npw * M,), float("nan"), device=dev)
+    a.w_partials, a.b_partials, a.b_stride, a.b_off = ptr(wp), ptr(bp), M, 0
+    check(lib.trunet_conv_wgrad(a, st), "wgrad")
+    gw, gb = torch.empty(numel, device=dev), torch.empty(M, device=dev)
+    check(lib.trunet_reduce_partials(ptr(gw), ptr(wp), npw, numel, 0, st), "reduce")
+    check(lib.trunet_reduce_partials(ptr(gb), ptr(bp), npw, M, 0, st), "reduce")
+    torch.cuda.synchronize()
+    dz = dy.double()
+    if two:
+        dz = ca.double()[:, None, None] * dz + cb.double()[:, None, None] * z.double() + cc.double()[:, None, None]
+    dz = dz.clone()
+    dz[:, :, N:] = 0
+    ref = torch.zeros(numel, dtype=torch.float64, device=dev)
+    for (t, sc, sh, C, Ls, pm, po, pdv, bn, wo) in info:
+        act = t.double()
+        if bn:
+            act = torch.relu(act * sc.double()[:, None, None] + sh.double()[:, None, None])
+        for p in range(P):
+            qn = p * pm + po
+            if qn < 0 or qn % pdv or qn // pdv >= Ls:
+                continue
+            contrib = dz[:, p] @ act[:, qn // pdv].T          # (M, C)
+            idx = (torch.arange(M, device=dev)[:, None] * a.ldw_m + torch.arange(C, device=dev)[None, :] * a.ldw_c + wo)
+            ref.index_put_((idx.reshape(-1),), contrib.reshape(-1), accumulate=True)
+    err = float((gw.double() - ref).norm() / ref.norm())
+    assert err < 1e-5, err
+    errb = float((gb.double() - dz.sum((1, 2))).norm() / dz.sum((1, 2)).norm())
+    assert errb < 1e-5, errb
+
+
+@pytest.mark.parametrize("N", [300, 777])
+def test_thin_wgrad_last_transposed_conv(N):
+    # decoder.5 ConvTranspose1d(8, 8, 5, stride 2, padding 1): taps kk at q = (p + 1 - kk) / 2
+    _thin_wgrad_case(N, 17, 8, False, [(8, 8, 1, 1 - kk, 2, True, "a") for kk in range(5)])
+
+
+def test_thin_wgrad_first_conv():
+    # encoder.0 Conv1d(4, 64, 5, stride 2, padding 1): taps kk at q = 2 p + kk - 1
+    _thin_wgrad_case(300, 8, 64, False, [(4, 17, 2, kk - 1, 1, False, "x") for kk in range(5)])
+
+
+def test_thin_wgrad_last_pointwise():
+    # decoder.5 Conv1d(128 -> 8, k = 1) over [x1 | skip], BatchNorm backward on dz
+    _thin_wgrad_case(520, 6, 8, True, [(64, 6, 1, 0, 1, True, None), (64, 6, 1, 0, 1, False, None)])

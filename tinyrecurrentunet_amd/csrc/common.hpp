@@ -15,6 +15,9 @@ static inline int trunet_launch_status() {
     return e == hipSuccess ? TRUNET_OK : TRUNET_ELAUNCH;
 }
 
+// wgrad_small.hip: vector-ALU weight gradient of the thin layers; TRUNET_ENOTSUP when the shape is not thin
+int trunet_launch_wgrad_small(const trunet_wgrad_args* h, hipStream_t st);
+
 // sum over the 32 lanes that share (lane >> 5)
 __device__ __forceinline__ float half_wave_sum(float v) {
     v += __shfl_xor(v, 16);

@@ -621,6 +621,18 @@ int plan_gemm(const trunet_gemm_args* h, GemmPlan* pl) {
                 int nbw = (int)((budget - fixed) / (2 * slot));
                 if (nbw > 4) nbw = 4;
                 pl->nw = 8; pl->nb = nbw; pl->lds = fixed + (size_t)nbw * 2 * slot;
+            } else if (wide_ok && wide_kind && two && kc == 32 && (h->NP % 256) == 0) {
+                // two-tensor prologue: 16-row chunks halve the slot, which can make the wide variant fit
+                // (transposed-conv data gradient 64 x (3 x 64): 46 -> 54 TF)
+                int kpad16 = 0;
+                for (int s = 0; s < h->nseg; ++s) kpad16 += (h->seg[s].nchan + 15) / 16 * 16;
+                const size_t slot16 = (size_t)16 * NT * sizeof(float) * 2;
+                const size_t fixed16 = (size_t)kpad16 * rs * 128 + (size_t)nchan_total * 16 + 4 * 32 * rs * sizeof(float);
+                if (fixed16 + 2 * 2 * slot16 <= budget) {
+                    int nbw = (int)((budget - fixed16) / (2 * slot16));
+                    if (nbw > 4) nbw = 4;
+                    pl->kc = 16; pl->nw = 8; pl->nb = nbw; pl->lds = fixed16 + (size_t)nbw * 2 * slot16;
+                }
             }
             pl->epl = (h->epi & TRUNET_EPI_MASK) ? ((h->epi & TRUNET_EPI_ACCUM) ? 2 : 1) : 0;
             return TRUNET_OK;
@@ -1062,6 +1074,15 @@ extern "C" int trunet_conv_wgrad(const trunet_wgrad_args* h, void* stream) {
         allrows += srp;
         ntot += sg.nchan;
         if (srp > maxsrp) maxsrp = srp;
+    }
+    {   // thin layers (<= 8 rows of dz, or <= 4 channels per segment): stream them on the vector ALU
+        int maxc = 0;
+        for (int s = 0; s < h->nseg; ++s) maxc = h->seg[s].nchan > maxc ? h->seg[s].nchan : maxc;
+        static const bool small_ok = !(getenv("TRUNET_WGRAD_SMALL") && getenv("TRUNET_WGRAD_SMALL")[0] == '0');
+        if (small_ok && (maxc <= 4 || (h->M <= 8 && maxc <= 8))) {
+            const int rc = trunet_launch_wgrad_small(h, (hipStream_t)stream);
+            if (rc != TRUNET_ENOTSUP) return rc;
+        }
     }
     // segments with pos_div > 1 are the taps of a strided transposed conv: at most ceil(nseg/stride) are valid at
     // one position (and they have equal channel counts); otherwise every segment may be valid

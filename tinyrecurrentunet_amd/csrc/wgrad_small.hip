@@ -1,0 +1,183 @@
+// Weight gradient of the thin layers (<= 8 output rows, or <= 4 source channels per tap): decoder.5's
+// ConvTranspose1d(8->8, k5) and Conv1d(128->8), and encoder.0's Conv1d(4->64, k5).  On the MFMA kernel these are
+// 3/4 (or 7/8) padding and pay a DMA-ring tile per 32 frames; here they are pure streams on the vector ALU.
+//
+//   dW[m][c][seg] = sum_{p, n<N} dz[m][p][n] * pro_seg(src_seg[c][q_seg(p)][n])
+//
+// grid = (256 partial images, roles); a role = (MB rows of dz) x (one segment, or all taps of one small tensor) x
+// (CB of its channels): every thread keeps its accumulators in registers, walks (position, 256-frame chunk) items with 16-byte loads (frames are contiguous), and
+// the block reduces its accumulators once at the end into its part of the partial image (trunet_reduce_partials
+// sums the images exactly as for conv_wgrad_kernel).
+#include "common.hpp"
+
+namespace {
+
+constexpr int WS_GRID = TRUNET_NUM_CU;
+
+// NS = segments per role: 1, or TRUNET_MAX_SEG = every segment (the taps of one small tensor: dz is read once)
+template <int MB, int CB, int NS>
+__global__ __launch_bounds__(256) void wgrad_small_kernel(const trunet_wgrad_args a, const int ngm, const int ngc_max) {
+    __shared__ float red[4][NS * MB * CB + MB];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // role -> (m group, channel group, first segment)
+    int role = blockIdx.y;
+    const int mg = role % ngm; role /= ngm;
+    const int cg = role % ngc_max;
+    const int sfirst = (NS == 1) ? role / ngc_max : 0;
+    const int ns = (NS == 1) ? 1 : a.nseg;
+    const int m0 = mg * MB, c0 = cg * CB;
+    if (c0 >= a.seg[sfirst].nchan) return;              // this segment has fewer channel groups (uniform)
+    const bool two = a.a_mode == TRUNET_PRO_BNBWD;
+    const bool bias_role = (sfirst == 0 && cg == 0);
+
+    float ka[MB], kb[MB], kc[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+        const int m = m0 + i;
+        const bool ok = m < a.M;
+        const int ch = min(m, a.M - 1) + a.a_m_off;
+        ka[i] = ok ? (two ? a.ac0[ch] : 1.f) : 0.f;
+        kb[i] = (ok && two) ? a.ac1[ch] : 0.f;
+        kc[i] = (ok && two) ? a.ac2[ch] : 0.f;
+    }
+    // prologue coefficients: per channel, taken from the first segment of the role (taps share their tensor)
+    float s0[CB], s1[CB], slo[CB];
+    {
+        const trunet_seg& sg = a.seg[sfirst];
+#pragma unroll
+        for (int j = 0; j < CB; ++j) {
+            const int ci = min(c0 + j, sg.nchan - 1);
+            const bool on = sg.mode == TRUNET_PRO_BNRELU;
+            s0[j] = on ? sg.c0[ci] : 1.f;
+            s1[j] = on ? sg.c1[ci] : 0.f;
+            slo[j] = on ? 0.f : -3.0e38f;
+        }
+    }
+    float acc[NS][MB][CB], bsum[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+        bsum[i] = 0.f;
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+#pragma unroll
+            for (int j = 0; j < CB; ++j) acc[k][i][j] = 0.f;
+    }
+
+    const int nch = a.NP / 256;
+    const int items = a.P * nch;
+    const size_t dstr = (size_t)a.a_L * a.NP;           // dz channel stride
+    for (int it = blockIdx.x * 4 + wave; it < items; it += gridDim.x * 4) {
+        const int pi = it / nch;
+        const int p = a.p_begin + pi;
+        const int n = (it - pi * nch) * 256 + 4 * lane;
+        bool valid[NS];
+        int qs[NS];
+        bool any = bias_role;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const trunet_seg& sg = a.seg[min(sfirst + k, a.nseg - 1)];
+            const int qn = p * sg.pos_mul + sg.pos_off;
+            qs[k] = qn / sg.pos_div;
+            valid[k] = (k < ns) && (qn >= 0) && (qn - qs[k] * sg.pos_div == 0) && (qs[k] < sg.L);
+            any = any || valid[k];
+        }
+        if (!any) continue;                             // uniform
+        const float* pdz = a.a0 + ((size_t)(min(m0, a.M - 1) + a.a_m_off) * a.a_L + p + a.a_pos_off) * a.NP + n;
+        const float* pz1 = two ? a.a1 + (pdz - a.a0) : pdz;
+        f32x4 dz[MB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const size_t o = (size_t)min(i, a.M - 1 - min(m0, a.M - 1)) * dstr;
+            dz[i] = *(const f32x4*)(pdz + o);
+            if (two) {
+                const f32x4 zz = *(const f32x4*)(pz1 + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dz[i][e] = fmaf(ka[i], dz[i][e], fmaf(kb[i], zz[e], kc[i]));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dz[i][e] *= ka[i];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e >= a.N) dz[i][e] = 0.f;
+        }
+        if (bias_role) {
+#pragma unroll
+            for (int i = 0; i < MB; ++i) bsum[i] += (dz[i][0] + dz[i][1]) + (dz[i][2] + dz[i][3]);
+        }
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            if (valid[k]) {
+                const trunet_seg& sg = a.seg[min(sfirst + k, a.nseg - 1)];
+                const size_t sstr = (size_t)sg.L * a.NP;        // source channel stride
+                const float* psrc = sg.src0 + ((size_t)min(c0, sg.nchan - 1) * sg.L + qs[k]) * a.NP + n;
+#pragma unroll
+                for (int j = 0; j < CB; ++j) {
+                    f32x4 v = *(const f32x4*)(psrc + (size_t)min(j, sg.nchan - 1 - min(c0, sg.nchan - 1)) * sstr);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], s0[j], s1[j]), slo[j]);
+#pragma unroll
+                    for (int i = 0; i < MB; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[k][i][j] = fmaf(dz[i][e], v[e], acc[k][i][j]);
+                }
+            }
+        }
+    }
+    // ---- block reduction (4 waves x 64 lanes) and this block's entries of the partial image
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+#pragma unroll
+            for (int j = 0; j < CB; ++j) {
+                const float v = wave_sum(acc[k][i][j]);
+                if (lane == 0) red[wave][(k * MB + i) * CB + j] = v;
+            }
+        const float b = wave_sum(bsum[i]);
+        if (lane == 0) red[wave][NS * MB * CB + i] = b;
+    }
+    __syncthreads();
+    float* img = a.w_partials + (size_t)blockIdx.x * a.w_numel;
+    for (int idx = tid; idx < NS * MB * CB + MB; idx += 256) {
+        const float v = (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]);
+        if (idx < NS * MB * CB) {
+            const int k = idx / (MB * CB), r = idx - k * (MB * CB);
+            const int i = r / CB, j = r - i * CB;
+            const int m = m0 + i, ci = c0 + j;
+            if (k < ns) {
+                const trunet_seg& sg = a.seg[sfirst + k];
+                if (m < a.M && ci < sg.nchan)
+                    img[(size_t)(m + a.w_m_off) * a.ldw_m + (size_t)ci * a.ldw_c + sg.woff] = v;
+            }
+        } else if (bias_role && a.b_partials) {
+            const int m = m0 + (idx - NS * MB * CB);
+            if (m < a.M) a.b_partials[(size_t)blockIdx.x * a.b_stride + a.b_off + m] = v;
+        }
+    }
+}
+
+}  // namespace
+
+// called by trunet_conv_wgrad (gemm_conv.hip) for the thin shapes; returns TRUNET_ENOTSUP when the shape is not thin
+int trunet_launch_wgrad_small(const trunet_wgrad_args* h, hipStream_t st) {
+    int maxc = 0;
+    bool same = true;       // every segment is a tap of the same tensor with the same prologue
+    for (int s = 0; s < h->nseg; ++s) {
+        maxc = h->seg[s].nchan > maxc ? h->seg[s].nchan : maxc;
+        same = same && h->seg[s].src0 == h->seg[0].src0 && h->seg[s].nchan == h->seg[0].nchan &&
+               h->seg[s].mode == h->seg[0].mode && h->seg[s].c0 == h->seg[0].c0 && h->seg[s].c1 == h->seg[0].c1;
+    }
+    if (maxc <= 4 && same) {                    // encoder.0 Conv1d(4 -> 64, k5): 4 rows of dz x all taps per role
+        const int ngm = (h->M + 3) / 4;
+        hipLaunchKernelGGL((wgrad_small_kernel<4, 4, TRUNET_MAX_SEG>), dim3(WS_GRID, ngm), dim3(256), 0, st, *h, ngm, 1);
+        return trunet_launch_status();
+    }
+    if (h->M <= 8 && maxc <= 8) {               // decoder.5 ConvTranspose1d(8 -> 8, k5): one tap per role
+        hipLaunchKernelGGL((wgrad_small_kernel<8, 8, 1>), dim3(WS_GRID, h->nseg), dim3(256), 0, st, *h, 1, 1);
+        return trunet_launch_status();
+    }
+    return TRUNET_ENOTSUP;
+}
