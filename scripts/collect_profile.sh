@@ -1,0 +1,19 @@
+#!/bin/bash
+# Run ON THE GPU BOX (through gpurun): kernel-trace statistics and the two HBM-traffic PMC passes of the default
+# bench step, each in its own rocprofv3 run (counters are never combined with other trace domains).
+#   bash scripts/collect_profile.sh <tag>     -> gpurun_out/prof_<tag>/{stats,fetch,write}/...
+set -e
+TAG=${1:-x}
+REPO=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o s -- python3 "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/stats.log" 2>&1
+echo "stats pass done"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -o f -- python3 "$REPO/bench.py" --steps 1 --warmup 1 --no-cpu-baseline > "$OUT/fetch.log" 2>&1
+echo "FETCH_SIZE pass done"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -o w -- python3 "$REPO/bench.py" --steps 1 --warmup 1 --no-cpu-baseline > "$OUT/write.log" 2>&1
+echo "WRITE_SIZE pass done"
+# keep what travels back small: the per-dispatch traces are large, the summaries are what profiles/ keeps
+find "$OUT" -name "*kernel_trace.csv" -size +20M -delete || true
+ls -la "$OUT"/*/* | head -30

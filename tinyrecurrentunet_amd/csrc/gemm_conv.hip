@@ -279,7 +279,7 @@ __global__ __launch_bounds__(64 * NW, (EPL == 0 || NW == 8) ? 2 : 1) void conv_g
         transform(tf, tslot);
         it_next<KC, FT>(a, tf);
         tslot = 1;
-        asm volatile("" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // a raw s_barrier does not wait for the LDS writes above
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
 
@@ -957,7 +957,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const trunet_wgrad_a
             for (int d = 0; d < NB; ++d) issue_dma(min(t0 + d, t1 - 1), d);
             wait_vmcnt_any((NB - 1) * LPW);
             transform(t0, 0);
-            asm volatile("" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // a raw s_barrier does not wait for the LDS writes above
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             int slot = 0;

@@ -24,12 +24,15 @@
 #include <type_traits>
 #include "common.hpp"
 
+#ifndef PWB_ABL      // diagnostic builds only (scripts/ubench_pwbwd.py): 1 no epilogue loads, 2 no epilogue stores,
+#define PWB_ABL 0    // 4 no prologue pass, 8 no DMA refill, 16 no weight-gradient MFMAs, 32 no data-gradient MFMAs
+#endif
+
 namespace {
 
 constexpr int WFC = 32;          // frames per tile
 constexpr int PMAXT = 4;         // weight-gradient accumulator tiles per wave (waves 0-3)
-constexpr int PD = 2;            // dz DMA row groups per wave   (M <= 128)
-constexpr int PS = 3;            // source DMA row groups per wave (sum of channels <= 192)
+constexpr int PSW = 6;           // source DMA row groups per loader wave (sum of channels <= 192)
 constexpr int PWB_GRID = TRUNET_NUM_CU;
 constexpr int PWB_SHARE = 2;     // partial statistics rows per workgroup
 
@@ -89,7 +92,7 @@ struct DRun {
 };
 
 // AK: k-pairs of the data-gradient A fragments = padded dz rows / 2 (32 for M <= 64, 64 for M <= 128)
-// SEC: data-gradient waves carry a second row tile (six row tiles over four waves)
+// SEC: data-gradient waves carry a second row tile (six row tiles over four waves); it never has statistics
 template <int AK, bool SEC>
 __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args A, const PwbSched sch, const int NB,
                                                         const int rows) {
@@ -103,11 +106,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
     constexpr int MA = 2 * AK;                // padded dz rows
     constexpr int nrt = MA / 32;
     constexpr int DZR = 2 * MA;               // rows of the dz block (dy, z)
-    constexpr int Gd = MA / 8;
-    const int Gs = (rows - DZR) / 8;
-    const int PPW = (Gd - wave + 7) / 8;      // this wave's dz row groups
-    const int SPW = (Gs - wave + 7) / 8;      // this wave's source row groups
-    const int LPW = PPW * 2 + SPW;            // this wave's DMA instructions per tile
+    constexpr int PDW = MA / 32;              // dz row groups (8 rows) per loader wave: g = wave + 4 i
     const int SLOT = rows * WFC;              // floats per slot
 
     float* R_lds = smem;
@@ -134,20 +133,44 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
             base += sg.nchan;
         }
     }
-    float bsum[PD];
-#pragma unroll
-    for (int i = 0; i < PD; ++i) bsum[i] = 0.f;
-
     const int nfc = a.NP / WFC;
     const int total_tiles = a.P * nfc;
     const int t_begin = (int)(((long long)blockIdx.x * total_tiles) / gridDim.x);
     const int t_end = (int)(((long long)(blockIdx.x + 1) * total_tiles) / gridDim.x);
     __syncthreads();
 
-    // ---- the tile pipeline, shared by both roles: begin_run(p, sbase) once per run of tiles with equal p,
-    // compute(t, S, n0) between the prologue pass of tile t+1 and the barrier that releases tile t's slot
-    auto pipeline = [&](auto begin_run, auto compute) __attribute__((always_inline)) {
-        if (t_begin >= t_end) return;
+    // Both roles walk the same runs of tiles (equal position p) with the same barrier sequence:
+    //   [run prologue] B  { [tile t: everything that reads LDS slot t]  B  [register / global work] } ...  B
+    if (wave < 4) {
+        // =================== loader + weight-gradient role
+        const int Gs = (rows - DZR) / 8;
+        const int SPW = (Gs - wave + 3) / 4;      // source row groups of this wave (<= PSW)
+        const int LPW = 2 * PDW + SPW;            // DMA instructions per tile
+        // output tiles g = wave + 4 i -> (row tile g % nrt = wave % nrt, k tile g / nrt)
+        const int my_rt = wave % nrt;
+        int t_seg[PMAXT], t_ct[PMAXT];
+#pragma unroll
+        for (int i = 0; i < PMAXT; ++i) {
+            int kt = (wave + 4 * i) / nrt;
+            t_seg[i] = -1; t_ct[i] = 0;
+#pragma unroll
+            for (int s = 0; s < TRUNET_MAX_SEG; ++s) {
+                if (s < a.nseg && t_seg[i] < 0 && kt >= 0) {
+                    const int nt = (a.seg[s].nchan + 31) / 32;
+                    if (kt < nt) { t_seg[i] = s; t_ct[i] = kt; }
+                    else kt -= nt;
+                }
+            }
+        }
+        f32x16 acc[PMAXT];
+#pragma unroll
+        for (int i = 0; i < PMAXT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        float bsum[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bsum[i] = 0.f;
+
         const int pc = lane & 7;
         int t0 = t_begin;
         while (t0 < t_end) {
@@ -184,28 +207,33 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
                     if (j < a.nseg) rb += (a.seg[sl[j]].nchan + 31) & ~31;
                 }
             }
-            // per-lane source pointers (frame 0 of this lane's row, logical piece folded in) and coefficient rows
-            const float* pd[PD];      // dy rows
-            const float* pzr[PD];     // z rows
-            const float* ps[PS];      // source rows
-            int cidx[PS];
+            int rb_run[PMAXT];       // first LDS row of tile i's source rows in this run, -1: segment not valid at p
 #pragma unroll
-            for (int i = 0; i < PD; ++i) {
-                pd[i] = a.a0; pzr[i] = a.a0;
-                if (i < PPW) {
-                    const int r = 8 * (wave + 8 * i) + (lane >> 3);
-                    const int lc = pc ^ ((r >> 1) & 7);
-                    const int m = min(r, a.M - 1) + a.a_m_off;
-                    const size_t off = ((size_t)m * a.a_L + p + a.a_pos_off) * a.NP + 4 * lc;
-                    pd[i] = a.a0 + off;
-                    pzr[i] = a.a1 + off;
-                }
+            for (int i = 0; i < PMAXT; ++i) {
+                int sb = -1;
+#pragma unroll
+                for (int s = 0; s < TRUNET_MAX_SEG; ++s) if (t_seg[i] == s) sb = sbase[s];
+                rb_run[i] = sb >= 0 ? sb + t_ct[i] * 32 : -1;
+            }
+            // per-lane source pointers (frame 0 of this lane's row, logical piece folded in) and coefficient rows
+            const float* pd[4];       // dy rows  (PDW <= 4 used; a dependent bound here makes hipcc drop the host stub)
+            const float* pzr[4];      // z rows
+            const float* ps[PSW];     // source rows
+            int cidx[PSW];
+#pragma unroll
+            for (int i = 0; i < PDW; ++i) {
+                const int r = 8 * (wave + 4 * i) + (lane >> 3);
+                const int lc = pc ^ ((r >> 1) & 7);
+                const int m = min(r, a.M - 1) + a.a_m_off;
+                const size_t off = ((size_t)m * a.a_L + p + a.a_pos_off) * a.NP + 4 * lc;
+                pd[i] = a.a0 + off;
+                pzr[i] = a.a1 + off;
             }
 #pragma unroll
-            for (int i = 0; i < PS; ++i) {
+            for (int i = 0; i < PSW; ++i) {
                 ps[i] = a.a0; cidx[i] = 0;
                 if (i < SPW) {
-                    const int g = wave + 8 * i;
+                    const int g = wave + 4 * i;
                     int rb = 0, sidx = sl[0], q = sq[0], ch0 = 0;
 #pragma unroll
                     for (int j = 0; j < TRUNET_MAX_SEG; ++j) {
@@ -225,84 +253,110 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
                     cidx[i] = cb + ci;
                 }
             }
-            begin_run(p, sbase);
 
             auto issue_dma = [&](int t, int slot) __attribute__((always_inline)) {
                 const int n0 = (t - pi * nfc) * WFC;
                 float* dst = R_lds + (size_t)slot * SLOT;
 #pragma unroll
-                for (int i = 0; i < PD; ++i) {
-                    if (i < PPW) {
-                        const int g = wave + 8 * i;
-                        __builtin_amdgcn_global_load_lds(pd[i] + n0, (lds_ptr_t)(dst + g * 256), 16, 0, 0);
-                        __builtin_amdgcn_global_load_lds(pzr[i] + n0, (lds_ptr_t)(dst + (MA / 8 + g) * 256), 16, 0, 0);
-                    }
+                for (int i = 0; i < PDW; ++i) {
+                    const int g = wave + 4 * i;
+                    __builtin_amdgcn_global_load_lds(pd[i] + n0, (lds_ptr_t)(dst + g * 256), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(pzr[i] + n0, (lds_ptr_t)(dst + (MA / 8 + g) * 256), 16, 0, 0);
                 }
 #pragma unroll
-                for (int i = 0; i < PS; ++i) {
+                for (int i = 0; i < PSW; ++i) {
                     if (i < SPW) {
-                        const int g = wave + 8 * i;
+                        const int g = wave + 4 * i;
                         __builtin_amdgcn_global_load_lds(ps[i] + n0, (lds_ptr_t)(dst + (DZR / 8 + g) * 256), 16, 0, 0);
                     }
                 }
             };
-            // prologue pass on this thread's own pieces of tile t
-            auto transform = [&](int t, int slot) __attribute__((always_inline)) {
+            // in-place prologue of one 8-row group of tile t (this thread's own DMA pieces): part < PDW: dz rows
+            // (BatchNorm backward, zero frames >= N, bias sums); part >= PDW: source rows (BatchNorm + ReLU)
+            auto tpart = [&](int part, int t, int slot) __attribute__((always_inline)) {
                 const int n0 = (t - pi * nfc) * WFC;
                 float* dst = R_lds + (size_t)slot * SLOT;
+                if (part < PDW) {
 #pragma unroll
-                for (int i = 0; i < PD; ++i) {
-                    if (i < PPW) {
-                        const int r = 8 * (wave + 8 * i) + (lane >> 3);
-                        const int lc = pc ^ ((r >> 1) & 7);
-                        float* pz = dst + r * WFC + 4 * pc;
-                        f32x4 v = *(f32x4*)pz;
-                        const f32x4 k = CA[r];
-                        const f32x4 z = *(const f32x4*)(pz + MA * WFC);
+                    for (int i = 0; i < PDW; ++i) {
+                        if (i == part) {
+                            const int r = 8 * (wave + 4 * i) + (lane >> 3);
+                            const int lc = pc ^ ((r >> 1) & 7);
+                            float* pz = dst + r * WFC + 4 * pc;
+                            f32x4 v = *(f32x4*)pz;
+                            const f32x4 k = CA[r];
+                            const f32x4 z = *(const f32x4*)(pz + MA * WFC);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaf(k[0], v[e], fmaf(k[1], z[e], k[2]));
-                        float sacc = 0.f;
+                            for (int e = 0; e < 4; ++e) v[e] = fmaf(k[0], v[e], fmaf(k[1], z[e], k[2]));
+                            float sacc = 0.f;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if (n0 + 4 * lc + e >= a.N) v[e] = 0.f;
-                            sacc += v[e];
+                            for (int e = 0; e < 4; ++e) {
+                                if (n0 + 4 * lc + e >= a.N) v[e] = 0.f;
+                                sacc += v[e];
+                            }
+                            bsum[i] += sacc;
+                            *(f32x4*)pz = v;
                         }
-                        bsum[i] += sacc;
-                        *(f32x4*)pz = v;
                     }
-                }
+                } else {
 #pragma unroll
-                for (int i = 0; i < PS; ++i) {
-                    if (i < SPW) {
-                        const f32x4 k = CB[cidx[i]];
-                        float* pz = dst + (DZR + 8 * (wave + 8 * i) + (lane >> 3)) * WFC + 4 * pc;
-                        f32x4 v = *(f32x4*)pz;
+                    for (int i = 0; i < PSW; ++i) {
+                        if (i == part - PDW && i < SPW) {
+                            const f32x4 k = CB[cidx[i]];
+                            float* pz = dst + (DZR + 8 * (wave + 4 * i) + (lane >> 3)) * WFC + 4 * pc;
+                            f32x4 v = *(f32x4*)pz;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], k[0], k[1]), k[2]);
-                        *(f32x4*)pz = v;
+                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], k[0], k[1]), k[2]);
+                            *(f32x4*)pz = v;
+                        }
                     }
                 }
             };
 
-            // ---- pipeline over tiles [t0, t1): NB tiles in flight, first one transformed
+            // ---- run prologue: NB tiles in flight, first one transformed
             for (int d = 0; d < NB; ++d) issue_dma(min(t0 + d, t1 - 1), d);
             pwb_wait_vmcnt((NB - 1) * LPW);
-            transform(t0, 0);
-            asm volatile("" ::: "memory");
+            if (!(PWB_ABL & 4)) {
+#pragma unroll
+                for (int part = 0; part < PDW + PSW; ++part) tpart(part, t0, 0);
+            }
+            // the prologue pass' LDS writes must have completed before another wave reads them: a raw s_barrier
+            // does not wait for them
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             int slot = 0;
             for (int t = t0; t < t1; ++t) {
-                if (t + 1 < t1) {
-                    pwb_wait_vmcnt((NB - 2) * LPW);
-                    transform(t + 1, (slot + 1 == NB) ? 0 : slot + 1);
+                const float* S = R_lds + (size_t)slot * SLOT;
+                const int nslot = (slot + 1 == NB) ? 0 : slot + 1;
+                const bool more = t + 1 < t1;
+                const int ra = my_rt * 32 + c;
+                // four frame groups of MFMAs; the prologue pass of tile t+1 runs in their shadow, a few row groups
+                // after each
+#pragma unroll
+                for (int q = 0; q < WFC / 8; ++q) {
+                    const f32x4 av = *(const f32x4*)(S + pwb_off(ra, 2 * q + h));
+#pragma unroll
+                    for (int i = 0; i < PMAXT; ++i) {
+                        if (rb_run[i] >= 0 && !(PWB_ABL & 16)) {
+                            const f32x4 bv = *(const f32x4*)(S + pwb_off(rb_run[i] + c, 2 * q + h));
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[i], 0, 0, 0);
+                        }
+                    }
+                    if (more && !(PWB_ABL & 4)) {
+                        if (q == 0) pwb_wait_vmcnt((NB - 2) * LPW);      // tile t+1 has landed
+                        tpart(q, t + 1, nslot);
+                        tpart(q + 4, t + 1, nslot);
+                        if (PDW + PSW > 8) tpart(q + 8, t + 1, nslot);
+                    }
                 }
-                compute(t, R_lds + (size_t)slot * SLOT, pwb_uniform((t - pi * nfc) * WFC));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // tile t+1's prologue writes have landed
+                __builtin_amdgcn_s_barrier();                // every LDS read of tile t is done
                 asm volatile("" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                issue_dma(min(t + NB, t1 - 1), slot);        // refill the slot just released
-                slot = (slot + 1 == NB) ? 0 : slot + 1;
+                if (!(PWB_ABL & 8)) issue_dma(min(t + NB, t1 - 1), slot);        // refill the slot just released
+                slot = nslot;
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("" ::: "memory");
@@ -310,58 +364,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
             asm volatile("" ::: "memory");
             t0 = t1;
         }
-    };
-
-    if (wave < 4) {
-        // =================== weight-gradient role: tiles g = wave + 4 i -> (row tile g % nrt = wave % nrt, k tile g / nrt)
-        const int my_rt = wave % nrt;
-        int t_seg[PMAXT], t_ct[PMAXT];
-#pragma unroll
-        for (int i = 0; i < PMAXT; ++i) {
-            int kt = (wave + 4 * i) / nrt;
-            t_seg[i] = -1; t_ct[i] = 0;
-#pragma unroll
-            for (int s = 0; s < TRUNET_MAX_SEG; ++s) {
-                if (s < a.nseg && t_seg[i] < 0 && kt >= 0) {
-                    const int nt = (a.seg[s].nchan + 31) / 32;
-                    if (kt < nt) { t_seg[i] = s; t_ct[i] = kt; }
-                    else kt -= nt;
-                }
-            }
-        }
-        f32x16 acc[PMAXT];
-#pragma unroll
-        for (int i = 0; i < PMAXT; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-        int rb_run[PMAXT];       // first LDS row of tile i's source rows in this run, -1: segment not valid at p
-        pipeline(
-            [&](int, const int* sbase) __attribute__((always_inline)) {
-#pragma unroll
-                for (int i = 0; i < PMAXT; ++i) {
-                    int sb = -1;
-#pragma unroll
-                    for (int s = 0; s < TRUNET_MAX_SEG; ++s) if (t_seg[i] == s) sb = sbase[s];
-                    rb_run[i] = sb >= 0 ? sb + t_ct[i] * 32 : -1;
-                }
-            },
-            [&](int, const float* S, int) __attribute__((always_inline)) {
-                const int ra = my_rt * 32 + c;
-#pragma unroll
-                for (int q = 0; q < WFC / 8; ++q) {
-                    const f32x4 av = *(const f32x4*)(S + pwb_off(ra, 2 * q + h));
-#pragma unroll
-                    for (int i = 0; i < PMAXT; ++i) {
-                        if (rb_run[i] >= 0) {
-                            const f32x4 bv = *(const f32x4*)(S + pwb_off(rb_run[i] + c, 2 * q + h));
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[i], 0, 0, 0);
-                        }
-                    }
-                }
-            });
-        // this workgroup's partial image of dW
+        // this workgroup's partial image of dW, db
         float* img = a.w_partials + (size_t)blockIdx.x * a.w_numel;
 #pragma unroll
         for (int i = 0; i < PMAXT; ++i) {
@@ -376,8 +379,20 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
                 }
             }
         }
+        if (a.b_partials) {
+#pragma unroll
+            for (int i = 0; i < PDW; ++i) {
+                float v = bsum[i];
+                v += __shfl_xor(v, 4);
+                v += __shfl_xor(v, 2);
+                v += __shfl_xor(v, 1);
+                const int row = 8 * (wave + 4 * i) + (lane >> 3);
+                if ((lane & 7) == 0 && row < a.M)
+                    a.b_partials[(size_t)blockIdx.x * a.b_stride + a.b_off + row] = v;
+            }
+        }
     } else {
-        // =================== data-gradient role
+        // =================== data-gradient role (no DMA, no prologue pass: LDS reads, MFMAs, epilogue)
         const int j = wave - 4;
         auto make_unit = [&](int rt, int period, int phase, int share) __attribute__((always_inline)) {
             DUnit u;
@@ -395,7 +410,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
             u.seg = pwb_uniform(u.seg); u.ct = pwb_uniform(u.ct); u.cb = pwb_uniform(u.cb); u.flags = pwb_uniform(u.flags);
             return u;
         };
-        auto load_af = [&](const DUnit& u, float (&af)[AK]) {
+        auto load_af = [&](const DUnit& u, float (&af)[AK]) __attribute__((always_inline)) {
             const trunet_seg& sg = a.seg[max(u.seg, 0)];
             const int ch = 32 * u.ct + c;
             const bool chok = u.seg >= 0 && ch < sg.nchan;
@@ -422,42 +437,48 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
             }
             return r;
         };
-        // one row tile of one tile: MFMAs over the dz rows, then the epilogue; FL = the segment's TRUNET_DG_* flags
-        auto dgrad = [&](auto FLc, const DUnit& u, const DRun& dr, const float (&af)[AK], float (&st1)[16],
-                         float (&st2)[16], const float* S, int n0) __attribute__((always_inline)) {
-            constexpr int FL = decltype(FLc)::value;
+        // State of the row tile whose epilogue is pending: accumulator and epilogue operands (registers only).
+        f32x16 dacc;
+        float zv[16], ov[16];
+        // head: hand-issued epilogue operand loads (uniform row base + per-lane offset keeps 64-bit addresses out of
+        // the VGPR budget), then the MFMAs over the dz rows
+        auto dgrad_head = [&](const DUnit& u, const DRun& dr, const float (&af)[AK], const float* S, int n0)
+                              __attribute__((always_inline)) {
             const float* zb = pwb_uniform(dr.zb);
-            float* ob = pwb_uniform(dr.ob);
+            const float* ob = pwb_uniform(dr.ob);
             const size_t dstride = pwb_uniform(dr.dstride);
-            // epilogue operands: hand-issued (uniform row base + per-lane offset keeps 64-bit addresses out of the
-            // VGPR budget, and the compiler would drain the DMA ring at their first use); waited for after the MFMAs
-            float zv[16], ov[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) { zv[r] = 0.f; ov[r] = 0.f; }
-            if (FL & TRUNET_DG_MASK) {
+            if ((u.flags & TRUNET_DG_MASK) && !(PWB_ABL & 1)) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float* rp = zb + (size_t)((r & 3) + 8 * (r >> 2)) * dstride + n0;
                     asm volatile("global_load_dword %0, %1, %2" : "=v"(zv[r]) : "v"(dr.voff), "s"(rp) : "memory");
                 }
             }
-            if (FL & TRUNET_DG_ACCUM) {
+            if ((u.flags & TRUNET_DG_ACCUM) && !(PWB_ABL & 1)) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float* rp = ob + (size_t)((r & 3) + 8 * (r >> 2)) * dstride + n0;
                     asm volatile("global_load_dword %0, %1, %2" : "=v"(ov[r]) : "v"(dr.voff), "s"(rp) : "memory");
                 }
             }
-            f32x16 dacc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) dacc[r] = 0.f;
             const float* Sb = S + h * WFC + (c & 3);
             const int cpc = c >> 2;
 #pragma unroll
-            for (int kk = 0; kk < AK; ++kk) {
+            for (int kk = 0; kk < ((PWB_ABL & 32) ? 1 : AK); ++kk) {
                 const float b = Sb[kk * (2 * WFC) + 4 * (cpc ^ (kk & 7))];
                 dacc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], b, dacc, 0, 0, 0);
             }
+        };
+        // tail: accumulate / ReLU mask / statistics / store; FL = the segment's TRUNET_DG_* flags
+        auto dgrad_tail = [&](auto FLc, const DUnit& u, const DRun& dr, float (&st1)[16], float (&st2)[16], int n0)
+                              __attribute__((always_inline)) {
+            constexpr int FL = decltype(FLc)::value;
+            float* ob = pwb_uniform(dr.ob);
+            const size_t dstride = pwb_uniform(dr.dstride);
             // The stores below are inline asm: the compiler's hazard recogniser does not pad between the last MFMA
             // (16 passes) and an asm instruction that reads its result, so wait it out here (>= 19 wait states).
             asm volatile("s_nop 15\n\ts_nop 7" : "+v"(dacc) :: "memory");
@@ -486,7 +507,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
                     val = (fmaf(k[0], zv[r], k[1]) > 0.f) ? val : 0.f;
                 }
                 float* rp = ob + (size_t)ml * dstride + n0;
-                asm volatile("global_store_dword %0, %1, %2" :: "v"(dr.voff), "v"(val), "s"(rp) : "memory");
+                if (!(PWB_ABL & 2)) asm volatile("global_store_dword %0, %1, %2" :: "v"(dr.voff), "v"(val), "s"(rp) : "memory");
                 if (FL & TRUNET_DG_STATS) {
                     const float x = fin ? val : 0.f;
                     st1[r] += x;
@@ -494,68 +515,85 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
                 }
             }
         };
-        auto dgrad_any = [&](const DUnit& u, const DRun& dr, const float (&af)[AK], float (&st1)[16], float (&st2)[16],
-                             int t, const float* S, int n0) __attribute__((always_inline)) {
-            if (!dr.valid || ((t & u.mask) != u.phase)) return;
-            constexpr int S_ = TRUNET_DG_STORE, M_ = TRUNET_DG_MASK, T_ = TRUNET_DG_STATS, C_ = TRUNET_DG_ACCUM;
-            if (u.flags == S_) dgrad(std::integral_constant<int, S_>(), u, dr, af, st1, st2, S, n0);
-            else if (u.flags == (S_ | M_ | T_)) dgrad(std::integral_constant<int, S_ | M_ | T_>(), u, dr, af, st1, st2, S, n0);
-            else if (u.flags == (S_ | M_ | T_ | C_)) dgrad(std::integral_constant<int, S_ | M_ | T_ | C_>(), u, dr, af, st1, st2, S, n0);
-            else dgrad(std::integral_constant<int, S_ | M_ | C_>(), u, dr, af, st1, st2, S, n0);
-        };
-        auto write_stats = [&](const DUnit& u, const float (&st1)[16], const float (&st2)[16]) {
-            if (u.seg < 0 || !(u.flags & TRUNET_DG_STATS)) return;
-            const trunet_dgrad_out& dg = A.dg[u.seg];
-            const int nch = a.seg[u.seg].nchan;
+        float sa1[16], sa2[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float s1 = half_wave_sum(st1[r]);
-                const float s2 = half_wave_sum(st2[r]);
-                const int ch = 32 * u.ct + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (c == 0 && ch < nch) {
-                    float* pp = dg.partials + ((size_t)(blockIdx.x * PWB_SHARE + u.share) * nch + ch) * 2;
-                    pp[0] = s1;
-                    pp[1] = s2;
-                }
-            }
+        for (int r = 0; r < 16; ++r) { sa1[r] = 0.f; sa2[r] = 0.f; }
+        auto tail_primary = [&](const DUnit& u, const DRun& dr, int n0) __attribute__((always_inline)) {
+            constexpr int S_ = TRUNET_DG_STORE, M_ = TRUNET_DG_MASK, T_ = TRUNET_DG_STATS, C_ = TRUNET_DG_ACCUM;
+            if (u.flags == S_) dgrad_tail(std::integral_constant<int, S_>(), u, dr, sa1, sa2, n0);
+            else if (u.flags == (S_ | M_ | T_)) dgrad_tail(std::integral_constant<int, S_ | M_ | T_>(), u, dr, sa1, sa2, n0);
+            else if (u.flags == (S_ | M_ | T_ | C_)) dgrad_tail(std::integral_constant<int, S_ | M_ | T_ | C_>(), u, dr, sa1, sa2, n0);
+            else dgrad_tail(std::integral_constant<int, S_ | M_ | C_>(), u, dr, sa1, sa2, n0);
+        };
+        auto tail_secondary = [&](const DUnit& u, const DRun& dr, int n0) __attribute__((always_inline)) {
+            constexpr int S_ = TRUNET_DG_STORE, M_ = TRUNET_DG_MASK, C_ = TRUNET_DG_ACCUM;      // never statistics
+            if (u.flags == S_) dgrad_tail(std::integral_constant<int, S_>(), u, dr, sa1, sa2, n0);
+            else dgrad_tail(std::integral_constant<int, S_ | M_ | C_>(), u, dr, sa1, sa2, n0);
+        };
+        auto active = [&](const DUnit& u, const DRun& dr, int t) __attribute__((always_inline)) {
+            return dr.valid && ((t & u.mask) == u.phase);
         };
 
         const DUnit u1 = make_unit(sch.rt[j], sch.period[j], sch.phase[j], sch.share[j]);
         const DUnit u2 = make_unit(SEC ? sch.rt2[j] : -1, sch.period2[j], sch.phase2[j], sch.share2[j]);
         float af1[AK], af2[SEC ? AK : 1];
-        float sa1[16], sa2[16], sb1[SEC ? 16 : 1], sb2[SEC ? 16 : 1];
         load_af(u1, af1);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { sa1[r] = 0.f; sa2[r] = 0.f; }
-        if constexpr (SEC) {
-            load_af(u2, af2);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { sb1[r] = 0.f; sb2[r] = 0.f; }
-        }
-        DRun r1, r2;
-        pipeline(
-            [&](int p, const int*) __attribute__((always_inline)) {
-                r1 = begin_unit(u1, p);
-                if constexpr (SEC) r2 = begin_unit(u2, p);
-            },
-            [&](int t, const float* S, int n0) __attribute__((always_inline)) {
-                dgrad_any(u1, r1, af1, sa1, sa2, t, S, n0);
-                if constexpr (SEC) dgrad_any(u2, r2, af2, sb1, sb2, t, S, n0);
-            });
-        write_stats(u1, sa1, sa2);
-        if constexpr (SEC) write_stats(u2, sb1, sb2);
-    }
+        if constexpr (SEC) load_af(u2, af2);
 
-    if (a.b_partials) {
+        int t0 = t_begin;
+        while (t0 < t_end) {
+            const int pi = t0 / nfc;
+            const int p = a.p_begin + pi;
+            const int t1 = min(t_end, (pi + 1) * nfc);
+            const DRun r1 = begin_unit(u1, p);
+            DRun r2 = r1;
+            if constexpr (SEC) r2 = begin_unit(u2, p);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();                     // tile t0 staged and transformed
+            asm volatile("" ::: "memory");
+            int slot = 0;
+            for (int t = t0; t < t1; ++t) {
+                const float* S = R_lds + (size_t)slot * SLOT;
+                const int n0 = pwb_uniform((t - pi * nfc) * WFC);
+                int pending = 0;          // which unit's epilogue waits for the barrier (0 none, 1, 2)
+                if (active(u1, r1, t)) { dgrad_head(u1, r1, af1, S, n0); pending = 1; }
+                if constexpr (SEC) {
+                    if (active(u2, r2, t)) {
+                        if (pending) tail_primary(u1, r1, n0);
+                        dgrad_head(u2, r2, af2, S, n0);
+                        pending = 2;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                // every LDS read of tile t is done
+                asm volatile("" ::: "memory");
+                // register-only epilogue: overlaps the other waves' next tile
+                if (pending == 1) tail_primary(u1, r1, n0);
+                if constexpr (SEC) {
+                    if (pending == 2) tail_secondary(u2, r2, n0);
+                }
+                slot = (slot + 1 == NB) ? 0 : slot + 1;
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();                     // ring is reused by the next run of tiles
+            asm volatile("" ::: "memory");
+            t0 = t1;
+        }
+        // BatchNorm-backward statistics of the primary row tile's source rows
+        if (u1.seg >= 0 && (u1.flags & TRUNET_DG_STATS)) {
+            const trunet_dgrad_out& dg = A.dg[u1.seg];
+            const int nch = a.seg[u1.seg].nchan;
 #pragma unroll
-        for (int i = 0; i < PD; ++i) {
-            float v = bsum[i];
-            v += __shfl_xor(v, 4);
-            v += __shfl_xor(v, 2);
-            v += __shfl_xor(v, 1);
-            const int row = 8 * (wave + 8 * i) + (lane >> 3);
-            if ((lane & 7) == 0 && i < PPW && row < a.M)
-                a.b_partials[(size_t)blockIdx.x * a.b_stride + a.b_off + row] = v;
+            for (int r = 0; r < 16; ++r) {
+                const float s1 = half_wave_sum(sa1[r]);
+                const float s2 = half_wave_sum(sa2[r]);
+                const int ch = 32 * u1.ct + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (c == 0 && ch < nch) {
+                    float* pp = dg.partials + ((size_t)(blockIdx.x * PWB_SHARE + u1.share) * nch + ch) * 2;
+                    pp[0] = s1;
+                    pp[1] = s2;
+                }
+            }
         }
     }
 }
@@ -588,7 +626,7 @@ extern "C" int trunet_pw_bwd(const trunet_pwbwd_args* H, void* stream) {
         ktiles += sg.nchan / 32;
         ntot += sg.nchan;
     }
-    if (ktiles * (MA / 32) > 4 * PMAXT || ntot > 8 * 8 * PS) return TRUNET_ENOTSUP;
+    if (ktiles * (MA / 32) > 4 * PMAXT || ntot > 4 * 8 * PSW) return TRUNET_ENOTSUP;
     PwbSched sch;
     for (int j = 0; j < 4; ++j) {
         sch.rt[j] = -1; sch.period[j] = 1; sch.phase[j] = 0; sch.share[j] = 0;
@@ -601,6 +639,15 @@ extern "C" int trunet_pw_bwd(const trunet_pwbwd_args* H, void* stream) {
         for (int j = 0; j < 4; ++j) sch.rt[j] = j;
     } else if (ktiles == 6) {   // row tiles 0-3 as above; 4, 5 by waves (0,1) on even and (2,3) on odd tiles
         if (MA != 64) return TRUNET_ENOTSUP;
+        // row tiles 4, 5 are secondary units: their segment must not ask for statistics
+        {
+            int kt = 0;
+            for (int s = 0; s < h->nseg; ++s) {
+                const int nt = h->seg[s].nchan / 32;
+                if (kt + nt > 4 && (H->dg[s].flags & TRUNET_DG_STATS)) return TRUNET_ENOTSUP;
+                kt += nt;
+            }
+        }
         sec = true;
         for (int j = 0; j < 4; ++j) {
             sch.rt[j] = j;
