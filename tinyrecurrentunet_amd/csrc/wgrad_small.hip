@@ -4,7 +4,7 @@
 //
 //   dW[m][c][seg] = sum_{p, n<N} dz[m][p][n] * pro_seg(src_seg[c][q_seg(p)][n])
 //
-// grid = (256 partial images, roles); a role = (MB rows of dz) x (one segment, or all taps of one small tensor) x
+// grid = (roles, 256 partial images); a role = (MB rows of dz) x (one segment, or all taps of one small tensor) x
 // (CB of its channels): every thread keeps its accumulators in registers, walks (position, 256-frame chunk) items with 16-byte loads (frames are contiguous), and
 // the block reduces its accumulators once at the end into its part of the partial image (trunet_reduce_partials
 // sums the images exactly as for conv_wgrad_kernel).
@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const trunet_wgrad_arg
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // role -> (m group, channel group, first segment)
-    int role = blockIdx.y;
+    int role = blockIdx.x;          // roles vary fastest: blocks that run together re-read the same rows from L2
     const int mg = role % ngm; role /= ngm;
     const int cg = role % ngc_max;
     const int sfirst = (NS == 1) ? role / ngc_max : 0;
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const trunet_wgrad_arg
     const int nch = a.NP / 256;
     const int items = a.P * nch;
     const size_t dstr = (size_t)a.a_L * a.NP;           // dz channel stride
-    for (int it = blockIdx.x * 4 + wave; it < items; it += gridDim.x * 4) {
+    for (int it = blockIdx.y * 4 + wave; it < items; it += gridDim.y * 4) {
         const int pi = it / nch;
         const int p = a.p_begin + pi;
         const int n = (it - pi * nch) * 256 + 4 * lane;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const trunet_wgrad_arg
         if (lane == 0) red[wave][NS * MB * CB + i] = b;
     }
     __syncthreads();
-    float* img = a.w_partials + (size_t)blockIdx.x * a.w_numel;
+    float* img = a.w_partials + (size_t)blockIdx.y * a.w_numel;
     for (int idx = tid; idx < NS * MB * CB + MB; idx += 256) {
         const float v = (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]);
         if (idx < NS * MB * CB) {
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const trunet_wgrad_arg
             }
         } else if (bias_role && a.b_partials) {
             const int m = m0 + (idx - NS * MB * CB);
-            if (m < a.M) a.b_partials[(size_t)blockIdx.x * a.b_stride + a.b_off + m] = v;
+            if (m < a.M) a.b_partials[(size_t)blockIdx.y * a.b_stride + a.b_off + m] = v;
         }
     }
 }
@@ -172,11 +172,11 @@ int trunet_launch_wgrad_small(const trunet_wgrad_args* h, hipStream_t st) {
     }
     if (maxc <= 4 && same) {                    // encoder.0 Conv1d(4 -> 64, k5): 4 rows of dz x all taps per role
         const int ngm = (h->M + 3) / 4;
-        hipLaunchKernelGGL((wgrad_small_kernel<4, 4, TRUNET_MAX_SEG>), dim3(WS_GRID, ngm), dim3(256), 0, st, *h, ngm, 1);
+        hipLaunchKernelGGL((wgrad_small_kernel<4, 4, TRUNET_MAX_SEG>), dim3(ngm, WS_GRID), dim3(256), 0, st, *h, ngm, 1);
         return trunet_launch_status();
     }
     if (h->M <= 8 && maxc <= 8) {               // decoder.5 ConvTranspose1d(8 -> 8, k5): one tap per role
-        hipLaunchKernelGGL((wgrad_small_kernel<8, 8, 1>), dim3(WS_GRID, h->nseg), dim3(256), 0, st, *h, 1, 1);
+        hipLaunchKernelGGL((wgrad_small_kernel<8, 8, 1>), dim3(h->nseg, WS_GRID), dim3(256), 0, st, *h, 1, 1);
         return trunet_launch_status();
     }
     return TRUNET_ENOTSUP;
