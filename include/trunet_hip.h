@@ -242,6 +242,10 @@ int trunet_stft_loss_fwd(const float* x, const float* y, const float* win, const
                          int B, int L, int n, int hop, void* stream);
 int trunet_stft_loss_bwd(const float* x, const float* y, const float* win, const float* tw, const float* coef,
                          float* gx, int B, int L, int n, int hop, void* stream);
+/* stft() of stft_loss.py:9-30: magnitudes sqrt(clamp(re^2+im^2, 1e-7)) of the Hann-windowed, centre/reflect-padded STFT
+ * as (B, 1 + L/hop, n/2 + 1); y / ymag may be NULL (one signal), else both signals share one complex FFT. */
+int trunet_stft_mag(const float* x, const float* y, const float* win, const float* tw, float* xmag, float* ymag, int B,
+                    int L, int n, int hop, void* stream);
 /* PhaseAwareMask.forward (phm.py:31-45 + R5) on interleaved complex64: out = sigmoid(beta(angle m - angle e)) |m| */
 int trunet_phm_fwd(const float* mix_ri, const float* est_ri, float* out, int64_t n, float beta, void* stream);
 

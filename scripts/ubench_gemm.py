@@ -3,6 +3,8 @@ import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tinyrecurrentunet_amd import _lib as L
+if os.environ.get("TRUNET_HIP_LIB"):      # diagnostic builds of the library
+    L.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.environ["TRUNET_HIP_LIB"])
 from tinyrecurrentunet_amd._lib import GemmArgs, make_seg, ptr, check, PRO_BNRELU, PRO_NONE, EPI_BIAS, EPI_STATS
 
 def run(N, Ln, K, M, mode, reps=5):

@@ -50,13 +50,22 @@ def _worker(rank, world, port, q):
 
 
 def test_two_rank_dp_step_matches_mean_of_local_gradients():
-    world, port = 2, 29500 + (os.getpid() % 1000)
+    import socket
+    world = 2
+    with socket.socket() as sk:            # a port that is free right now (a fixed one can be in TIME_WAIT)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     [p.start() for p in ps]
-    res = [q.get(timeout=300) for _ in range(world)]
-    [p.join(60) for p in ps]
+    try:
+        res = [q.get(timeout=300) for _ in range(world)]
+    finally:
+        [p.join(60) for p in ps]
+        codes = [p.exitcode for p in ps]
+        [p.kill() for p in ps if p.is_alive()]
+    assert all(c == 0 for c in codes), codes
     for rank, err, n, tgru_none in res:
         assert n == 298592 and tgru_none
         assert err < 1e-5, (rank, err)

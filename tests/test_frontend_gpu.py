@@ -151,3 +151,18 @@ def test_fused_adamw_matches_torch():
         assert abs(float(nsq) - tot) < 1e-4 * tot
     for p, q in zip(ps, qs):
         assert _rel(p, q) < 1e-5
+
+
+@pytest.mark.parametrize("fs,hop,wl", [(512, 50, 240), (1024, 120, 600), (2048, 240, 1200)])
+def test_stft_magnitudes_vs_reference_formula(fs, hop, wl):
+    """Module-level stft() (stft_loss.py:9-30): sqrt(clamp(re^2 + im^2, 1e-7)) of torch.stft with a Hann window of
+    win_length < n_fft, transposed to (B, frames, bins)."""
+    from oracle import stft_loss_ref as sr
+    from tinyrecurrentunet_amd import stft_loss as sl
+    torch.manual_seed(3)
+    x = torch.randn(3, 5000)
+    win = torch.hann_window(wl)
+    ref = sr.stft_mag(x.double(), fs, hop, wl, win.double())
+    got = sl.stft(x.cuda(), fs, hop, wl, win.cuda())
+    assert got.shape == ref.shape
+    assert _rel(got, ref) < 1e-5

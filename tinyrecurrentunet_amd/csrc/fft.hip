@@ -304,6 +304,32 @@ __global__ __launch_bounds__(256) void stft_loss_fwd_kernel(const float* __restr
     r = block_sum_f64((double)s3, red); if (threadIdx.x == 0) pp[2] = (float)r;
 }
 
+// stft() of stft_loss.py:9-30 for two signals at once: magnitudes sqrt(clamp(re^2 + im^2, 1e-7)) as (B, frames, bins)
+__global__ __launch_bounds__(256) void stft_mag_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                       const float* __restrict__ win, const cpx* __restrict__ tw,
+                                                       float* __restrict__ xmag, float* __restrict__ ymag, int L, int n,
+                                                       int logn, int hop, int nframes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    cpx* sa = (cpx*)smraw;
+    cpx* sb = sa + n;
+    const int f = blockIdx.x, b = blockIdx.y;
+    const float* xb = x + (size_t)b * L;
+    const float* yb = y + (size_t)b * L;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int j = reflect_idx(f * hop + i - n / 2, L);
+        const float w = win[i];
+        sa[i] = make_float2(w * xb[j], w * yb[j]);
+    }
+    const cpx* Z = fft_lds(sa, sb, n, logn, tw, false);
+    const size_t base = ((size_t)b * nframes + f) * (n / 2 + 1);
+    for (int k = threadIdx.x; k <= n / 2; k += 256) {
+        cpx X, Y;
+        split_pair(Z, k, n, X, Y);
+        xmag[base + k] = sqrtf(fmaxf(X.x * X.x + X.y * X.y, 1e-7f));
+        if (ymag) ymag[base + k] = sqrtf(fmaxf(Y.x * Y.x + Y.y * Y.y, 1e-7f));
+    }
+}
+
 // out[c] = sum_g partials[g*ncols + c], one block per column, fp64
 __global__ __launch_bounds__(256) void reduce_cols_kernel(const float* __restrict__ partials, int nparts, int ncols,
                                                           float* __restrict__ out) {
@@ -430,6 +456,16 @@ extern "C" int trunet_stft_loss_fwd(const float* x, const float* y, const float*
     const int nframes = 1 + L / hop;
     hipLaunchKernelGGL(stft_loss_fwd_kernel, dim3(nframes, B), dim3(256), 2 * n * sizeof(cpx), ST, x, y, win, (const cpx*)tw,
                        partials, L, n, logn, hop, nframes);
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_stft_mag(const float* x, const float* y, const float* win, const float* tw, float* xmag, float* ymag,
+                               int B, int L, int n, int hop, void* stream) {
+    const int logn = ilog2(n);
+    if (!x || !win || !tw || !xmag || B <= 0 || logn < 3 || n > 4096 || hop <= 0 || L <= n / 2) return TRUNET_EINVAL;
+    const int nframes = 1 + L / hop;
+    hipLaunchKernelGGL(stft_mag_kernel, dim3(nframes, B), dim3(256), 2 * n * sizeof(cpx), ST, x, y ? y : x, win,
+                       (const cpx*)tw, xmag, y ? ymag : nullptr, L, n, logn, hop, nframes);
     return trunet_launch_status();
 }
 

@@ -265,6 +265,10 @@ __global__ __launch_bounds__(64 * NW, (EPL == 0 || NW == 8) ? 2 : 1) void conv_g
                 *(f32x4*)(dst + ((LPW / NSRC) * wave8 + i) * 256 + 4 * lane) = v[i];
         };
 
+        // Two waves per SIMD: the second-dispatched half loses every issue arbitration at equal priority; one static
+        // s_setprio for it (no per-phase flips) is worth +19 % on the 64-row launches (pw 192 -> 64: 66 -> 79 TF) and
+        // is neutral at 128 rows.
+        if (NW == 8 && wave8 >= 4) __builtin_amdgcn_s_setprio(1);
         // ---- pipeline prologue
         it_enter_tile<KC, FT>(a, cur);
         ChunkIt ld = cur, ldlast = cur;

@@ -393,6 +393,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
         }
     } else {
         // =================== data-gradient role (no DMA, no prologue pass: LDS reads, MFMAs, epilogue)
+        // (s_setprio 1 for these waves was measured: 4 % slower at 128 channels, neutral at 64)
         const int j = wave - 4;
         auto make_unit = [&](int rt, int period, int phase, int share) __attribute__((always_inline)) {
             DUnit u;

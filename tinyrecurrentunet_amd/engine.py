@@ -97,7 +97,6 @@ class BNState:
         self.C = C
         self.scale, self.shift, self.mean, self.rstd = z(), z(), z(), z()
         self.ca, self.cb, self.cc = z(), z(), z()
-        self.dgamma, self.dbeta = z(), z()
         self.count = 0.0
         self.module = None
 
@@ -410,16 +409,44 @@ class TRUNetEngine:
     def _bn_bwd(self, w, st, nparts, grads, part_name="partials"):
         m = st.module
         part = w.flat(part_name, nparts * st.C * 2)
+        dgamma = torch.empty(st.C, device=part.device, dtype=torch.float32)   # handed to autograd: never workspace
+        dbeta = torch.empty(st.C, device=part.device, dtype=torch.float32)
         check(L.lib().trunet_bn_finalize_bwd(ptr(part), nparts, st.C, st.count, ptr(m.weight.data), ptr(st.mean),
-                                             ptr(st.rstd), ptr(st.dgamma), ptr(st.dbeta), ptr(st.ca), ptr(st.cb),
+                                             ptr(st.rstd), ptr(dgamma), ptr(dbeta), ptr(st.ca), ptr(st.cb),
                                              ptr(st.cc), L.stream()), "bn_finalize_bwd")
-        grads[m.weight] = st.dgamma.clone()
-        grads[m.bias] = st.dbeta.clone()
+        grads[m.weight] = dgamma
+        grads[m.bias] = dbeta
+
+    # ---- weight-gradient partial images: every conv / GRU weight and bias owns a slice of ONE buffer
+    # [nparts][total]; the launches write their per-workgroup partial images straight into it (image stride = total)
+    # and a single trunet_reduce_partials at the end of backward sums all of them (one launch instead of ~46).
+    def _wg_begin(self, w):
+        if getattr(self, "_wg_layout", None) is None:
+            off, lay = 0, {}
+            for p in self.net._active_params() if hasattr(self.net, "_active_params") else self.net.parameters():
+                lay[p] = off
+                off += (p.numel() + 63) // 64 * 64
+            self._wg_layout, self._wg_total = lay, off
+        self._wg_base = w.flat("wg_partials", L.lib().trunet_conv_wgrad_nparts() * self._wg_total)
+        self._wg_touched = {}
+
+    def _wg_slot(self, p):
+        """device pointer of parameter p's slice in partial image 0"""
+        self._wg_touched[id(p)] = p
+        return self._wg_base.data_ptr() + 4 * self._wg_layout[p]
+
+    def _wg_finish(self, grads):
+        lib = L.lib()
+        flat = torch.empty(self._wg_total, device=self._wg_base.device, dtype=torch.float32)   # fresh: autograd keeps it
+        check(lib.trunet_reduce_partials(ptr(flat), ptr(self._wg_base), lib.trunet_conv_wgrad_nparts(), self._wg_total,
+                                         0, L.stream()), "reduce")
+        for p in self._wg_touched.values():
+            o = self._wg_layout[p]
+            grads[p] = flat[o:o + p.numel()].view_as(p)
 
     def _wgrad(self, w, *, N, NP, P, M, dz, dz_L, dz_bn, W, ldw_m, ldw_c, segs, grads, bias=None, a_pos_off=0,
-               a_m_off=0, w_m_off=0, reduce=True, b_total=None, b_off=0, wgrad_out=None, bgrad_out=None, dz1=None):
+               a_m_off=0, w_m_off=0, b_off=0, dz1=None):
         lib = L.lib()
-        nparts = lib.trunet_conv_wgrad_nparts()
         numel = W.numel()
         a = WgradArgs()
         a.NP, a.N, a.P, a.p_begin = NP, N, P, 0
@@ -435,12 +462,11 @@ class TRUNetEngine:
             a.a1, a.ac0, a.ac1, a.ac2 = ptr(dz1), ptr(dz_bn.ca), ptr(dz_bn.cb), ptr(dz_bn.cc)
         else:
             a.a_mode = PRO_NONE
-        wp = w.flat("w_partials", nparts * 32768)
-        a.w_partials = ptr(wp)
-        bt = b_total if b_total is not None else M
-        bp = w.flat("b_partials", nparts * 512)
-        a.b_partials = ptr(bp)
-        a.b_stride, a.b_off = bt, b_off
+        a.w_numel = self._wg_total                      # image stride of the shared buffer
+        a.w_partials = self._wg_slot(W)
+        if bias is not None:
+            a.b_partials = self._wg_slot(bias)
+            a.b_stride, a.b_off = self._wg_total, b_off
         if PROFILE is not None:
             fl = 2.0 * N * M * sum(s.nchan * _seg_positions(s, 0, P) for s in segs)
             with _Timed("conv_wgrad_kernel<%s>" % ("true" if dz_bn is not None else "false"), fl,
@@ -448,17 +474,6 @@ class TRUNetEngine:
                 check(lib.trunet_conv_wgrad(a, L.stream()), "conv_wgrad")
         else:
             check(lib.trunet_conv_wgrad(a, L.stream()), "conv_wgrad")
-        if reduce:
-            gw = wgrad_out if wgrad_out is not None else torch.empty_like(W)
-            check(lib.trunet_reduce_partials(ptr(gw), ptr(wp), nparts, numel, 0, L.stream()), "reduce")
-            gb = bgrad_out if bgrad_out is not None else torch.empty(bt, device=W.device, dtype=torch.float32)
-            check(lib.trunet_reduce_partials(ptr(gb), ptr(bp), nparts, bt, 0, L.stream()), "reduce")
-            if wgrad_out is None:
-                grads[W] = gw
-            if bias is not None and bgrad_out is None:
-                grads[bias] = gb
-            return gw, gb
-        return None
 
     def _pw_bwd(self, w, *, N, NP, P, M, dz, dz1, dz_bn, W, bias, segs, outs, grads):
         """Fused backward of a Conv1d(k=1)+BatchNorm layer (trunet_pw_bwd): weight/bias gradient and, per source
@@ -477,11 +492,9 @@ class TRUNetEngine:
         aw.a0, aw.a1 = ptr(dz), ptr(dz1)
         aw.a_mode = PRO_BNBWD
         aw.ac0, aw.ac1, aw.ac2 = ptr(dz_bn.ca), ptr(dz_bn.cb), ptr(dz_bn.cc)
-        npw = lib.trunet_conv_wgrad_nparts()
-        wp = w.flat("w_partials", npw * 32768)
-        bp = w.flat("b_partials", npw * 512)
-        aw.w_partials, aw.b_partials = ptr(wp), ptr(bp)
-        aw.b_stride, aw.b_off = M, 0
+        aw.w_numel = self._wg_total                     # image stride of the shared buffer
+        aw.w_partials, aw.b_partials = self._wg_slot(W), self._wg_slot(bias)
+        aw.b_stride, aw.b_off = self._wg_total, 0
         a.W = ptr(W.data)
         nparts = lib.trunet_pw_bwd_nparts()
         stat_parts = []
@@ -509,12 +522,6 @@ class TRUNetEngine:
                 check(lib.trunet_pw_bwd(a, L.stream()), "pw_bwd")
         else:
             check(lib.trunet_pw_bwd(a, L.stream()), "pw_bwd")
-        gw = torch.empty_like(W)
-        gb = torch.empty(M, device=W.device, dtype=torch.float32)
-        check(lib.trunet_reduce_partials(ptr(gw), ptr(wp), npw, numel, 0, L.stream()), "reduce")
-        check(lib.trunet_reduce_partials(ptr(gb), ptr(bp), npw, M, 0, L.stream()), "reduce")
-        grads[W] = gw
-        grads[bias] = gb
         for bn, pname in stat_parts:
             self._bn_bwd(w, bn, nparts, grads, part_name=pname)
 
@@ -525,6 +532,7 @@ class TRUNetEngine:
         lib = L.lib()
         st = L.stream()
         grads = {}
+        self._wg_begin(w)
         gout = gout.contiguous()
         last = acts["dec5"]
         dyt = w.get("dy:dec5", (last.C, last.L, NP))
@@ -620,30 +628,17 @@ class TRUNetEngine:
             wih_p = getattr(gru, "weight_ih_l0" + sfx)
             bih_p = getattr(gru, "bias_ih_l0" + sfx)
             hseg = make_seg(hout.t[d * Hh:(d + 1) * Hh], Hh, Lg, pos_off=(1 if d else -1))
-            gw = torch.empty_like(whh)
-            gb = torch.empty_like(bhh)
-            nparts = lib.trunet_conv_wgrad_nparts()
             # rows 0..2H-1 (r, z) come from dgi, rows 2H..3H-1 (n) from dghn
             self._wgrad(w, N=N, NP=NP, P=Lg, M=2 * Hh, dz=dgi, dz_L=Lg, dz_bn=None, a_m_off=d * 3 * Hh, W=whh,
-                        ldw_m=Hh, ldw_c=1, segs=[hseg], grads=grads, reduce=False, b_total=3 * Hh, b_off=0)
+                        ldw_m=Hh, ldw_c=1, segs=[hseg], grads=grads, bias=bhh, b_off=0)
             self._wgrad(w, N=N, NP=NP, P=Lg, M=Hh, dz=dghn, dz_L=Lg, dz_bn=None, a_m_off=d * Hh, w_m_off=2 * Hh,
-                        W=whh, ldw_m=Hh, ldw_c=1, segs=[hseg], grads=grads, reduce=False, b_total=3 * Hh,
-                        b_off=2 * Hh)
-            check(lib.trunet_reduce_partials(ptr(gw), ptr(w.t["w_partials"]), nparts, whh.numel(), 0, st), "reduce")
-            check(lib.trunet_reduce_partials(ptr(gb), ptr(w.t["b_partials"]), nparts, 3 * Hh, 0, st), "reduce")
-            grads[whh], grads[bhh] = gw, gb
+                        W=whh, ldw_m=Hh, ldw_c=1, segs=[hseg], grads=grads, bias=bhh, b_off=2 * Hh)
             # input projection weights: rows of dgi for this direction (3H = 128 + 64)
-            gwi = torch.empty_like(wih_p)
-            gbi = torch.empty_like(bih_p)
             self._wgrad(w, N=N, NP=NP, P=Lg, M=2 * Hh, dz=dgi, dz_L=Lg, dz_bn=None, a_m_off=d * 3 * Hh, W=wih_p,
-                        ldw_m=gru.input_size, ldw_c=1, segs=[enc5.seg()], grads=grads, reduce=False,
-                        b_total=3 * Hh, b_off=0)
+                        ldw_m=gru.input_size, ldw_c=1, segs=[enc5.seg()], grads=grads, bias=bih_p, b_off=0)
             self._wgrad(w, N=N, NP=NP, P=Lg, M=Hh, dz=dgi, dz_L=Lg, dz_bn=None, a_m_off=d * 3 * Hh + 2 * Hh,
                         w_m_off=2 * Hh, W=wih_p, ldw_m=gru.input_size, ldw_c=1, segs=[enc5.seg()], grads=grads,
-                        reduce=False, b_total=3 * Hh, b_off=2 * Hh)
-            check(lib.trunet_reduce_partials(ptr(gwi), ptr(w.t["w_partials"]), nparts, wih_p.numel(), 0, st), "reduce")
-            check(lib.trunet_reduce_partials(ptr(gbi), ptr(w.t["b_partials"]), nparts, 3 * Hh, 0, st), "reduce")
-            grads[wih_p], grads[bih_p] = gwi, gbi
+                        bias=bih_p, b_off=2 * Hh)
         # data gradient of the projection -> dy of enc5's BN
         wih = w.t["wih"]
         dy5 = w.get("dy:enc5", (enc5.C, enc5.L, NP))
@@ -714,4 +709,5 @@ class TRUNetEngine:
         segs = [make_seg(xa.t, xa.C, xa.L, pos_mul=s_, pos_off=kk - pad, woff=kk) for kk in range(k)]
         self._wgrad(w, N=N, NP=NP, P=128, M=c0.out_channels, dz=dy, dz_L=128, dz_bn=None, W=c0.weight,
                     ldw_m=xa.C * k, ldw_c=k, segs=segs, grads=grads, bias=c0.bias)
+        self._wg_finish(grads)
         return grads

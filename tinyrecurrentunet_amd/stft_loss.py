@@ -18,6 +18,23 @@ def _padded_window(window, n):
     return w
 
 
+def stft(x, fft_size, hop_size, win_length, window):
+    """stft_loss.py:9-30: (B, L) -> magnitude spectrogram (B, frames, fft_size // 2 + 1) = sqrt(clamp(re^2 + im^2, 1e-7)).
+    Forward only: the training losses never materialise magnitudes (they use the fused three-sums kernel and
+    recompute the frame FFT in backward); this is the reference's stand-alone helper on the same LDS FFT."""
+    if not x.is_cuda:
+        raise L.TrunetHipError("tinyrecurrentunet_amd.stft_loss runs on MI355X only")
+    if x.requires_grad and torch.is_grad_enabled():
+        raise L.TrunetHipError("stft() is forward-only; differentiate through STFTLoss / MultiResolutionSTFTLoss")
+    x = x.detach().contiguous().float()
+    B, Ln = x.shape
+    win = _padded_window(window.to(x.device), fft_size)
+    out = torch.empty((B, 1 + Ln // hop_size, fft_size // 2 + 1), device=x.device, dtype=torch.float32)
+    check(L.lib().trunet_stft_mag(ptr(x), None, ptr(win), ptr(L.twiddles(fft_size, x.device)), ptr(out), None, B, Ln,
+                                  fft_size, hop_size, L.stream()), "stft_mag")
+    return out
+
+
 class _STFTLossFn(torch.autograd.Function):
     """(x, y) -> (sc, mag) of one resolution; gradient w.r.t. x only (y is the ground truth)."""
 
