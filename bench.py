@@ -233,17 +233,24 @@ def main():
         tot_ms, flops, n = agg[name]
         ach = flops / (tot_ms * 1e-3) / 1e12
         # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-        # separate runs, gfx950 correction 2*FETCH + WRITE; profiles/round1_c_pmc_traffic.json); null when absent
-        traffic = None
+        # separate runs, gfx950 correction 2*FETCH + WRITE; scripts/collect_profile.sh + summarize_profile.py): the
+        # newest profiles/*_pmc_traffic.json that knows the kernel; null when none does or the workload is not the default
+        traffic, traffic_src = None, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_c_pmc_traffic.json")))["kernels"]
-            if name in pmc and not (args.no_stft_loss or args.no_pcen or args.batch != 64 or args.seconds != 4.0):
-                traffic = round(pmc[name]["hbm_bytes_per_launch_corrected"])
+            import glob
+            if not (args.no_stft_loss or args.no_pcen or args.batch != 64 or args.seconds != 4.0):
+                for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+                    pmc = json.load(open(fn))["kernels"]
+                    if name in pmc:
+                        traffic = round(pmc[name]["hbm_bytes_per_launch_corrected"])
+                        traffic_src = os.path.basename(fn)
+                        break
         except Exception:
             traffic = None
         roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": traffic,
                 "traffic_GBps": (round(traffic / (tot_ms / n * 1e-3) / 1e9, 1) if traffic else None),
+                "traffic_source": traffic_src,
                 "launches_per_step": n, "avg_launch_ms": round(tot_ms / n, 4),
                 "kernel_ms_per_step": {k: round(v[0], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])},
                 "step_flop_frac_of_peak": round(value / world * FLOPS_PER_FRAME_STEP / 1e12 / PEAK_F32_TFLOPS, 4),
