@@ -96,9 +96,11 @@ def streaming(args, dev):
     net = hn.TRUNet(input_size=4).to(dev).eval()
     x = torch.randn(streams, 4, 257, device=dev)
     graphed = False
+    state = hn.TRUNetStreamState() if args.tgru else None       # --tgru: stateful time-recurrent block per stream
+    fwd = (lambda t: net.stream_step(t, state)[0]) if args.tgru else net
     with torch.no_grad():
         for _ in range(max(args.warmup, 2)):
-            net(x)
+            fwd(x)
         torch.cuda.synchronize()
         # the ~70 launches of one forward are launch-bound at this size: replay them as one hipGraph
         g = None
@@ -106,7 +108,7 @@ def streaming(args, dev):
             try:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    y = net(x)
+                    y = fwd(x)
                 g.replay()
                 torch.cuda.synchronize()
                 graphed = True
@@ -121,14 +123,15 @@ def streaming(args, dev):
                 g.replay()
             else:
                 x = torch.randn(streams, 4, 257, device=dev)
-                y = net(x)
+                y = fwd(x)
         torch.cuda.synchronize()
     dt = (time.time() - t0) / args.steps
     out = {"metric": "streaming forward real-time factor (1024 streams x 1 frame)", "value": round(streams * 0.008 / dt, 1),
            "unit": "x real time", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True, "dtype": "f32", "data": "synthetic",
            "frames_per_s": round(streams / dt, 1), "hip_graph": graphed,
-           "config": {"workload": "config/tiny.json TRU-Net eval forward, randn(1024,4,257) per step (rt.py protocol)"}}
+           "config": {"workload": "config/tiny.json TRU-Net eval forward%s, randn(1024,4,257) per step (rt.py protocol)" % (
+               " + stateful TGRU step (use_tgru streaming)" if args.tgru else "")}}
     print(json.dumps(out), flush=True)
 
 
@@ -144,6 +147,7 @@ def main():
     ap.add_argument("--no-pcen", action="store_true", help="ablation (BASELINE.json configs[4])")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and the gradient all-reduce even with one rank")
+    ap.add_argument("--tgru", action="store_true", help="with --streaming: run the TGRU block statefully (stream_step)")
     ap.add_argument("--streaming", action="store_true",
                     help="BASELINE.json configs[3]: 1-frame causal forward of 1024 concurrent streams (rt.py protocol)")
     args = ap.parse_args()

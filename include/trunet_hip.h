@@ -205,6 +205,11 @@ int trunet_gru_bwd(const float* dhout, const float* hout, const float* gates, co
                    const float* w_hh_rev, float* dgi, float* dghn, int H, int L, int NP, int N,
                    void* stream);
 
+/* One time step of a unidirectional nn.GRU cell (the TGRU of network.py:150 in stateful streaming use):
+ * gi = W_ih x + b_ih and gh = W_hh h + b_hh are [3H][L][NP] (two trunet_conv_gemm launches), h / h_new [H][L][NP];
+ * torch gate order r, z, n; h_new = (1 - z) n + z h. */
+int trunet_gru_cell(const float* gi, const float* gh, const float* h, float* h_new, int H, int L, int NP, void* stream);
+
 /* fused AdamW over a flat buffer (torch.optim.AdamW, train.py:68,140) */
 int trunet_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                  float beta2, float eps, float wd, int step, void* stream);

@@ -151,3 +151,24 @@ class TRUNet(nn.Module):
             x = self.decoder[i](x, skips[i])
             inter["dec%d" % i] = x
         return (x, inter) if return_intermediates else x
+
+    def stream_step(self, x, h=None):
+        """Stateful streaming with the TGRU block between FGRU and the decoder (docs/net.jpg): x is
+        one frame per stream (S, C_in, 257); every (stream, frequency position) is a sequence of the unidirectional
+        nn.GRU of network.py:150 advanced by one step; h (1, S*16, 128) is carried.  Build-defined (the reference never
+        calls TGRU, D6): parity for this path is against this restatement only."""
+        skips = []
+        for block in self.encoder:
+            x = block(x)
+            skips.append(x)
+        skips = skips[::-1]
+        x = self.FGRU(x.transpose(1, 2))                        # (S, 64, 16)
+        S = x.shape[0]
+        seq = x.permute(0, 2, 1).reshape(S * 16, 1, 64)
+        out, h = self.TGRU.GRU(seq, h)                          # (S*16, 1, 128)
+        y = self.TGRU.conv(out.transpose(1, 2))                 # (S*16, 64, 1)
+        x = y.reshape(S, 16, 64).permute(0, 2, 1).contiguous()  # (S, 64, 16)
+        x = self.decoder[0](x)
+        for i in range(1, 6):
+            x = self.decoder[i](x, skips[i])
+        return x, h

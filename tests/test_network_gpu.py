@@ -156,3 +156,27 @@ def test_block_forward_matches_reference_golden(golden, name):
     for bn_, b in mod.named_buffers():
         if b.is_floating_point():
             assert _rel(b, torch.tensor(g["buf:" + bn_])) < 1e-4, bn_
+
+
+def test_tgru_streaming_matches_oracle():
+    """Stateful streaming with the TGRU block: five consecutive frames of 37 streams, hidden state
+    carried, vs the fp64 oracle's nn.GRU stepping (build-defined path: the reference never calls TGRU)."""
+    from oracle import network_ref as nr, weights as W
+    ref, net = _nets(4, seed=7)
+    refd = W.fill_state_dict(nr.TRUNet(input_size=4), seed=7).double().eval()
+    net.eval()
+    rng = np.random.default_rng(5)
+    h, state = None, None
+    for t in range(5):
+        x = torch.tensor(rng.standard_normal((37, 4, 257)) * 0.5, dtype=torch.float32)
+        with torch.no_grad():
+            yd, h = refd.stream_step(x.double(), h)
+        y, state = net.stream_step(x.cuda(), state)
+        assert _rel(y, yd) < 1e-4, (t, _rel(y, yd))
+    assert state.steps == 5
+    # hidden state parity: oracle h is (1, S*16, 128) with row s*16 + l; ours [128][16][NP]
+    hh = state.h[:, :, :37].permute(2, 1, 0).reshape(37 * 16, 128)
+    assert _rel(hh, h[0]) < 1e-4
+    with pytest.raises(Exception):
+        net.train()
+        net.stream_step(x.cuda(), state)

@@ -98,6 +98,7 @@ def _declare(L):
         "trunet_dwconv_bwd": [p] * 14 + [i] * 7 + [p],
         "trunet_gru_fwd": [p, p, p, p, p, p, p, i, i, i, p],
         "trunet_gru_bwd": [p, p, p, p, p, p, p, i, i, i, i, p],
+        "trunet_gru_cell": [p, p, p, p, i, i, i, p],
         "trunet_adamw": [p, p, p, p, i64, f, f, f, f, f, i, p],
         "trunet_sumsq": [p, i64, p, p],
         "trunet_stft_features": [p, p, p, p, i, i, i, i, p],

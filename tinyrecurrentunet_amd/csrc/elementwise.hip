@@ -208,6 +208,32 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(
     }
 }
 
+// ---------------------------------------------------------------- one GRU time step (streaming TGRU)
+// gi = W_ih x + b_ih, gh = W_hh h + b_hh as [3H][R] rows (R = L*NP contiguous), torch gate order r, z, n:
+//   r = sigmoid(gi_r + gh_r), z = sigmoid(gi_z + gh_z), n = tanh(gi_n + r * gh_n), h' = (1 - z) n + z h
+__global__ __launch_bounds__(256) void gru_cell_kernel(const float* __restrict__ gi, const float* __restrict__ gh,
+                                                       const float* h, float* hn, int H,   // h may alias hn
+                                                      
+                                                       size_t R4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;      // float4 index inside one row block [H][R]
+    if (i >= (size_t)H * R4) return;
+    const size_t HR = (size_t)H * R4;
+    const f32x4* gi4 = (const f32x4*)gi;
+    const f32x4* gh4 = (const f32x4*)gh;
+    const f32x4 ir = gi4[i], iz = gi4[HR + i], in_ = gi4[2 * HR + i];
+    const f32x4 hr = gh4[i], hz = gh4[HR + i], hn_ = gh4[2 * HR + i];
+    const f32x4 hp = ((const f32x4*)h)[i];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float r = 1.f / (1.f + expf(-(ir[e] + hr[e])));
+        const float z = 1.f / (1.f + expf(-(iz[e] + hz[e])));
+        const float n = tanhf(in_[e] + r * hn_[e]);
+        o[e] = (1.f - z) * n + z * hp[e];
+    }
+    ((f32x4*)hn)[i] = o;
+}
+
 // ---------------------------------------------------------------- BatchNorm statistics -> affine
 __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __restrict__ partials, int nparts, int C,
                                                               double count, const float* __restrict__ gamma,
@@ -314,6 +340,15 @@ extern "C" int trunet_from_frames_last(const float* x, float* y, int N, int C, i
     if (!x || !y || N <= 0 || NP < N) return TRUNET_EINVAL;
     int R = C * L;
     hipLaunchKernelGGL(from_frames_last_kernel, dim3((NP + 31) / 32, (R + 31) / 32), dim3(32, 8), 0, ST, x, y, N, R, NP);
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_gru_cell(const float* gi, const float* gh, const float* h, float* h_new, int H, int L, int NP,
+                               void* stream) {
+    if (!gi || !gh || !h || !h_new || H <= 0 || L <= 0 || NP <= 0 || (NP % 4)) return TRUNET_EINVAL;
+    const size_t R4 = (size_t)L * NP / 4;
+    const size_t n = (size_t)H * R4;
+    hipLaunchKernelGGL(gru_cell_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ST, gi, gh, h, h_new, H, R4);
     return trunet_launch_status();
 }
 

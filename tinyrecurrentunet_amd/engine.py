@@ -360,7 +360,34 @@ class TRUNetEngine:
         return Act(hout, 2 * Hh, Lg)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, training):
+    def _tgru_step(self, w, cur, state, N, NP):
+        """One time step of the TGRU block (network.py:150, GRUBlock :45-58) per stream: every (stream, frequency
+        position) pair is a sequence whose hidden state h [128][16][NP] is carried in ``state`` between calls (the
+        paper-style use of the block; the reference constructs it and never calls it, D6)."""
+        lib = L.lib()
+        blk = self.net.TGRU
+        gru = blk.GRU
+        Hh, Lg = gru.hidden_size, cur.L
+        if gru.bidirectional or gru.input_size != cur.C:
+            raise L.TrunetHipError("TGRU streaming expects the unidirectional GRUBlock(64, 128, 64) of network.py:150")
+        if state.h is None or tuple(state.h.shape) != (Hh, Lg, NP):
+            state.h = torch.zeros((Hh, Lg, NP), device=cur.t.device, dtype=torch.float32)     # h0 = 0 like nn.GRU
+            state.n = N
+        if state.n != N:
+            raise L.TrunetHipError("stream state belongs to %d streams, got %d" % (state.n, N))
+        gi = w.get("tgru.gi", (3 * Hh, Lg, NP))
+        gh = w.get("tgru.gh", (3 * Hh, Lg, NP))
+        self._gemm(w, N=N, NP=NP, P=Lg, M=3 * Hh, out=gi, out_L=Lg, W=gru.weight_ih_l0.data, ldw_m=gru.input_size,
+                   ldw_c=1, segs=[cur.seg()], bias=gru.bias_ih_l0.data)
+        self._gemm(w, N=N, NP=NP, P=Lg, M=3 * Hh, out=gh, out_L=Lg, W=gru.weight_hh_l0.data, ldw_m=Hh, ldw_c=1,
+                   segs=[Act(state.h, Hh, Lg).seg()], bias=gru.bias_hh_l0.data)
+        # elementwise and in place (every element reads its own h): the state keeps its address, so a captured
+        # hipGraph of one step can be replayed frame after frame
+        check(lib.trunet_gru_cell(ptr(gi), ptr(gh), ptr(state.h), ptr(state.h), Hh, Lg, NP, L.stream()), "gru_cell")
+        state.steps += 1
+        return self._pw(w, "tgru", [Act(state.h, Hh, Lg)], blk.conv[0], blk.conv[1], N, NP, False)
+
+    def forward(self, x, training, tgru_state=None):
         net = self.net
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[2] == F_BINS
         x = x.contiguous()
@@ -389,6 +416,9 @@ class TRUNetEngine:
         gru = net.FGRU.GRU
         acts["hout"] = self._gru(w, cur, gru, N, NP, training)
         cur = acts["fgru"] = self._pw(w, "fgru", [acts["hout"]], net.FGRU.conv[0], net.FGRU.conv[1], N, NP, training)
+
+        if tgru_state is not None:
+            cur = acts["tgru"] = self._tgru_step(w, cur, tgru_state, N, NP)
 
         seq = net.decoder[0].FirstTrCNN
         cur = acts["dec0.pw"] = self._pw(w, "dec0.pw", [cur], seq[0], seq[1], N, NP, training)

@@ -182,6 +182,23 @@ class TRUNet(nn.Module):
         self.TGRU = GRUBlock(64, 128, 64, bidirectional=False)
         object.__setattr__(self, "_engine", None)
 
+    def stream_step(self, x, state=None):
+        """Stateful causal streaming with the time-recurrent block: ``x`` (streams, C_in, 257) is ONE
+        new STFT frame per stream; the encoder, FGRU and decoder run as in ``forward`` (eval mode) and the TGRU block
+        (network.py:150, constructed but never called by the reference, D6) runs one GRU time step per (stream,
+        frequency position) between FGRU and the decoder, as drawn in docs/net.jpg.  Returns (y, state); pass the
+        state back in with the next frame.  Inference only."""
+        _need_gpu(x)
+        if self.training:
+            raise _lib.TrunetHipError("stream_step is an inference path: call net.eval() first")
+        if self._engine is None:
+            object.__setattr__(self, "_engine", TRUNetEngine(self))
+        if state is None:
+            state = TRUNetStreamState()
+        with torch.no_grad():
+            out, _ = self._engine.forward(x.float(), False, tgru_state=state)
+        return out, state
+
     def _active_params(self):
         return [p for n, p in self.named_parameters() if not n.startswith("TGRU.")]
 
@@ -194,6 +211,13 @@ class TRUNet(nn.Module):
             return _TRUNetFn.apply(x, self._engine, self.training, *params)
         out, _ = self._engine.forward(x, self.training)
         return out
+
+
+class TRUNetStreamState:
+    """Hidden state of the TGRU block for ``TRUNet.stream_step``: h [128][16][NP] (frames-last), one column per stream."""
+
+    def __init__(self):
+        self.h, self.n, self.steps = None, 0, 0
 
 
 # train.py:22 imports this name (it does not exist in the reference either, SURVEY D12): alias only.
