@@ -147,7 +147,8 @@ def main():
     ap.add_argument("--no-pcen", action="store_true", help="ablation (BASELINE.json configs[4])")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and the gradient all-reduce even with one rank")
-    ap.add_argument("--tgru", action="store_true", help="with --streaming: run the TGRU block statefully (stream_step)")
+    ap.add_argument("--tgru", action="store_true",
+                    help="extension: TGRU block over time (use_tgru train step; with --streaming: stateful stream_step)")
     ap.add_argument("--streaming", action="store_true",
                     help="BASELINE.json configs[3]: 1-frame causal forward of 1024 concurrent streams (rt.py protocol)")
     args = ap.parse_args()
@@ -170,7 +171,7 @@ def main():
         return streaming(args, dev)
     cin = 3 if args.no_pcen else 4
     torch.manual_seed(0)                      # train.py:12-14
-    net = hn.TRUNet(input_size=cin).to(dev).train()
+    net = hn.TRUNet(input_size=cin, use_tgru=args.tgru).to(dev).train()      # --tgru: extension, not the headline config
     if use_dist:
         tdist.apply_gradient_allreduce(net)
     opt = optim.FusedAdamW(net.parameters(), lr=4e-4)
@@ -242,7 +243,7 @@ def main():
         traffic, traffic_src = None, None
         try:
             import glob
-            if not (args.no_stft_loss or args.no_pcen or args.batch != 64 or args.seconds != 4.0):
+            if not (args.tgru or args.no_stft_loss or args.no_pcen or args.batch != 64 or args.seconds != 4.0):
                 for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
                     pmc = json.load(open(fn))["kernels"]
                     if name in pmc:
@@ -268,7 +269,8 @@ def main():
                "config": {"workload": "config/tiny.json TRU-Net (C_in=%d%s), %d x %.0f s 16 kHz pairs per GPU, "
                                       "n_fft 512 hop 128, full fp32 train step%s" % (
                                           cin, " incl. PCEN" if cin == 4 else "", args.batch, args.seconds,
-                                          "" if stft_lambda else " WITHOUT MR-STFT loss"),
+                                          ("" if stft_lambda else " WITHOUT MR-STFT loss") +
+                                          (" WITH the TGRU block trained over time (use_tgru extension)" if args.tgru else "")),
                           "frames_per_gpu": frames, "global_batch": args.batch * world,
                           "parallelism": "dp%d" % world, "loss": float(loss.detach())},
                "roofline": roof, "cpu_baseline": cpu}

@@ -210,6 +210,27 @@ int trunet_gru_bwd(const float* dhout, const float* hout, const float* gates, co
  * torch gate order r, z, n; h_new = (1 - z) n + z h. */
 int trunet_gru_cell(const float* gi, const float* gh, const float* h, float* h_new, int H, int L, int NP, void* stream);
 
+/* ---- TGRU as a trained layer (network.py:150 used as drawn in docs/net.jpg; build-defined forward).
+ * The time axis of the recurrence is the FRAME axis, so the block works on "sequence-major" tensors
+ * y[c][t][s], s = b*Lf + l < S = B*Lf (padded to SP): every (utterance b, frequency position l) is one sequence.
+ * to:   y = max(scale[c] x + shift[c], relu ? 0 : -inf) of frames-last x[c][l][b*T + t] (scale == NULL: y = x); y = 0 for s >= S
+ * from: x = y (zsrc == NULL), or x = y * [scale z + shift > 0] with z = zsrc (same layout as x) and the BatchNorm-backward
+ *       sums of x: partials[trunet_from_seq_major_nparts()][C][2] = sum x, sum x (z - mean[c]). */
+int trunet_to_seq_major(const float* x, float* y, const float* scale, const float* shift, int relu, int C, int Lf, int T,
+                        int B, int NP, int SP, void* stream);
+int trunet_from_seq_major_nparts(int Lf, int T, int B);
+int trunet_from_seq_major(const float* y, float* x, const float* zsrc, const float* scale, const float* shift,
+                          const float* mean, float* partials, int C, int Lf, int T, int B, int NP, int SP, void* stream);
+/* time step t of nn.GRU (torch gate order r, z, n) on sequence-major tensors: gi_all [3H][T][SP] = W_ih x + b_ih,
+ * gh [3H][SP] = W_hh h_{t-1} + b_hh (trunet_conv_gemm), hs [H][T+1][SP] with h_{t} at position t+1 (position 0 = h_{-1} = 0),
+ * gates [4][H][T][SP] = r, z, n, gh_n (NULL in eval).  bwd: dhs [H][T+1][SP] holds dL/dh_t at position t+1 and receives
+ * the direct term dh_t z_t at position t; carry [H][SP] = W_hh^T dgh_{t+1} (NULL at t = T-1); writes dgi_all / dgh_all
+ * [3H][T][SP] rows of step t; sequences s >= S carry no gradient. */
+int trunet_tgru_cell_fwd(const float* gi_all, const float* gh, float* hs, float* gates, int H, int T, int t, int SP,
+                         void* stream);
+int trunet_tgru_cell_bwd(float* dhs, const float* carry, const float* hs, const float* gates, float* dgi_all,
+                         float* dgh_all, int H, int T, int t, int SP, int S, void* stream);
+
 /* fused AdamW over a flat buffer (torch.optim.AdamW, train.py:68,140) */
 int trunet_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                  float beta2, float eps, float wd, int step, void* stream);

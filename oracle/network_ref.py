@@ -152,6 +152,26 @@ class TRUNet(nn.Module):
             inter["dec%d" % i] = x
         return (x, inter) if return_intermediates else x
 
+    def forward_tgru(self, x, T):
+        """use_tgru (docs/net.jpg): x holds B utterances of T frames, (B*T, C_in, 257); the TGRU
+        GRUBlock (network.py:150, :45-58 forward) runs over time for every (utterance, frequency position) between
+        FGRU and the decoder.  Build-defined composition (the reference never calls TGRU, D6)."""
+        skips = []
+        for block in self.encoder:
+            x = block(x)
+            skips.append(x)
+        skips = skips[::-1]
+        x = self.FGRU(x.transpose(1, 2))                                   # (B*T, 64, 16)
+        N = x.shape[0]
+        B = N // T
+        seq = x.reshape(B, T, 64, 16).permute(0, 3, 1, 2).reshape(B * 16, T, 64)
+        y = self.TGRU(seq)                                                 # GRUBlock.forward: (B*16, 64, T)
+        x = y.reshape(B, 16, 64, T).permute(0, 3, 2, 1).reshape(N, 64, 16)
+        x = self.decoder[0](x)
+        for i in range(1, 6):
+            x = self.decoder[i](x, skips[i])
+        return x
+
     def stream_step(self, x, h=None):
         """Stateful streaming with the TGRU block between FGRU and the decoder (docs/net.jpg): x is
         one frame per stream (S, C_in, 257); every (stream, frequency position) is a sequence of the unidirectional

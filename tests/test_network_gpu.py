@@ -180,3 +180,34 @@ def test_tgru_streaming_matches_oracle():
     with pytest.raises(Exception):
         net.train()
         net.stream_step(x.cuda(), state)
+
+
+@pytest.mark.parametrize("B,T", [(3, 7), (2, 40)])
+def test_use_tgru_forward_backward_vs_oracle_f64(B, T):
+    """TGRU as a trained layer (use_tgru=True): forward and every gradient (TGRU's included) vs the fp64 oracle."""
+    from oracle import network_ref as nr, weights as W
+    from tinyrecurrentunet_amd import network as hn
+    refd = W.fill_state_dict(nr.TRUNet(input_size=4), seed=9).double()
+    net = hn.TRUNet(input_size=4, use_tgru=True)
+    net.load_state_dict(W.fill_state_dict(nr.TRUNet(input_size=4), seed=9).state_dict())
+    net.cuda()
+    N = B * T
+    x = torch.tensor(np.random.default_rng(N).standard_normal((N, 4, 257)) * 0.5, dtype=torch.float32)
+    cot = torch.tensor(np.random.default_rng(N + 1).standard_normal((N, 8, 257)), dtype=torch.float32)
+    refd.eval(); net.eval()
+    with torch.no_grad():
+        assert _rel(net(x.cuda(), frames_per_seq=T), refd.forward_tgru(x.double(), T)) < 1e-4
+    refd.train(); net.train()
+    yd = refd.forward_tgru(x.double(), T)
+    (yd * cot.double()).sum().backward()
+    y = net(x.cuda(), frames_per_seq=T)
+    assert _rel(y, yd) < 1e-4
+    (y * cot.cuda()).sum().backward()
+    pd = dict(refd.named_parameters())
+    errs, n = [], 0
+    for pn, p in net.named_parameters():
+        assert p.grad is not None, pn
+        n += p.numel()
+        _grad_close(p.grad, pd[pn].grad, pn, errs)
+    assert n == 381472                      # SURVEY 0: 381,472 parameters at C_in = 4 with TGRU
+    assert float(np.median(errs)) < 2.5e-2, float(np.median(errs))

@@ -234,6 +234,162 @@ __global__ __launch_bounds__(256) void gru_cell_kernel(const float* __restrict__
     ((f32x4*)hn)[i] = o;
 }
 
+// ---------------------------------------------------------------- TGRU: sequence-major layout and the time loop's cells
+// frames-last x[c][l][b*T + t]  <->  sequence-major y[c][t][s], s = b*Lf + l (every (utterance, frequency position) is
+// one sequence of the time-recurrent block, network.py:150).  32 x 32 (t, s... ) tiles through LDS; block = (32, 8).
+// to: y = max(sc[c] x + sh[c], lo) (BatchNorm+ReLU of the source, or identity when sc == NULL); y = 0 for s >= S.
+__global__ void to_seq_major_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ sc,
+                                    const float* __restrict__ sh, int Lf, int T, int B, int NP, int SP, float lo) {
+    __shared__ float tl[32][33];
+    const int c = blockIdx.z / Lf, l = blockIdx.z % Lf;
+    const int t0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const float a0 = sc ? sc[c] : 1.f, a1 = sc ? sh[c] : 0.f;
+    for (int i = ty; i < 32; i += 8) {          // read: t contiguous
+        const int b = b0 + i, t = t0 + tx;
+        float v = 0.f;
+        if (b < B && t < T) v = fmaxf(fmaf(x[((size_t)c * Lf + l) * NP + (size_t)b * T + t], a0, a1), lo);
+        tl[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {          // write: b varies fastest -> stride Lf in s
+        const int t = t0 + i, b = b0 + tx;
+        if (t < T && b < B) y[((size_t)c * T + t) * SP + (size_t)b * Lf + l] = tl[tx][i];
+    }
+}
+
+// from: x[c][l][b*T + t] = y[c][t][s] (raw), or with zsrc != NULL the backward of `to` with its BatchNorm+ReLU:
+// x = y * [sc z + sh > 0] plus per-block partial sums (sum x, sum x (z - mean)) -> partials[(blk)][C][2].
+__global__ void from_seq_major_kernel(const float* __restrict__ y, float* __restrict__ x, const float* __restrict__ zsrc,
+                                      const float* __restrict__ sc, const float* __restrict__ sh,
+                                      const float* __restrict__ mean, float* __restrict__ partials, int C, int Lf, int T,
+                                      int B, int NP, int SP) {
+    __shared__ float tl[32][33];
+    __shared__ float red[2][8];
+    const int c = blockIdx.z / Lf, l = blockIdx.z % Lf;
+    const int t0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    for (int i = ty; i < 32; i += 8) {
+        const int t = t0 + i, b = b0 + tx;
+        tl[tx][i] = (t < T && b < B) ? y[((size_t)c * T + t) * SP + (size_t)b * Lf + l] : 0.f;
+    }
+    __syncthreads();
+    float s1 = 0.f, s2 = 0.f;
+    const float a0 = zsrc ? sc[c] : 0.f, a1 = zsrc ? sh[c] : 0.f, mu = zsrc ? mean[c] : 0.f;
+    for (int i = ty; i < 32; i += 8) {
+        const int b = b0 + i, t = t0 + tx;
+        if (b < B && t < T) {
+            const size_t o = ((size_t)c * Lf + l) * NP + (size_t)b * T + t;
+            float v = tl[i][tx];
+            if (zsrc) {
+                const float z = zsrc[o];
+                v = (fmaf(a0, z, a1) > 0.f) ? v : 0.f;
+                s1 += v;
+                s2 = fmaf(v, z - mu, s2);
+            }
+            x[o] = v;
+        }
+    }
+    if (zsrc) {
+        // reduce over the 32 lanes of a row (threadIdx.x), then over the 8 rows
+        for (int m = 16; m > 0; m >>= 1) { s1 += __shfl_xor(s1, m, 32); s2 += __shfl_xor(s2, m, 32); }
+        if (tx == 0) { red[0][ty] = s1; red[1][ty] = s2; }
+        __syncthreads();
+        if (tx == 0 && ty == 0) {
+            float r1 = 0.f, r2 = 0.f;
+            for (int i = 0; i < 8; ++i) { r1 += red[0][i]; r2 += red[1][i]; }
+            // one partial row per (t block, b block, l): blocks of the same channel never collide
+            const size_t blk = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * Lf + l;
+            partials[(blk * C + c) * 2 + 0] = r1;
+            partials[(blk * C + c) * 2 + 1] = r2;
+        }
+    }
+}
+
+// time step t of nn.GRU forward on sequence-major tensors: gi_all [3H][T][SP] (= W_ih x + b_ih), gh [3H][SP]
+// (= W_hh h_{t-1} + b_hh), hs [H][T+1][SP] with hs[:, 0] = h_{-1} = 0 and h_t at position t+1;
+// gates [4][H][T][SP] = r, z, n, gh_n (training; may be NULL).
+__global__ __launch_bounds__(256) void tgru_cell_fwd_kernel(const float* __restrict__ gi_all, const float* __restrict__ gh,
+                                                            float* hs, float* __restrict__ gates, int H, int T, int t,
+                                                            int SP) {
+    const int s4 = SP / 4;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)H * s4) return;
+    const int j = (int)(i / s4), q = (int)(i % s4);
+    const f32x4* gi4 = (const f32x4*)gi_all;
+    const f32x4* gh4 = (const f32x4*)gh;
+    const size_t grow = (size_t)T * s4;                       // float4 stride between rows of gi_all
+    const f32x4 ir = gi4[(size_t)j * grow + (size_t)t * s4 + q];
+    const f32x4 iz = gi4[(size_t)(H + j) * grow + (size_t)t * s4 + q];
+    const f32x4 in_ = gi4[(size_t)(2 * H + j) * grow + (size_t)t * s4 + q];
+    const f32x4 hr = gh4[(size_t)j * s4 + q], hz = gh4[(size_t)(H + j) * s4 + q], hn_ = gh4[(size_t)(2 * H + j) * s4 + q];
+    f32x4* hs4 = (f32x4*)hs;
+    const size_t hrow = (size_t)(T + 1) * s4;
+    const f32x4 hp = hs4[(size_t)j * hrow + (size_t)t * s4 + q];
+    f32x4 r, z, n, o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        r[e] = 1.f / (1.f + expf(-(ir[e] + hr[e])));
+        z[e] = 1.f / (1.f + expf(-(iz[e] + hz[e])));
+        n[e] = tanhf(in_[e] + r[e] * hn_[e]);
+        o[e] = (1.f - z[e]) * n[e] + z[e] * hp[e];
+    }
+    hs4[(size_t)j * hrow + (size_t)(t + 1) * s4 + q] = o;
+    if (gates) {
+        f32x4* g4 = (f32x4*)gates;
+        const size_t plane = (size_t)H * T * s4;
+        const size_t o_ = ((size_t)j * T + t) * s4 + q;
+        g4[o_] = r; g4[plane + o_] = z; g4[2 * plane + o_] = n; g4[3 * plane + o_] = hn_;
+    }
+}
+
+// time step t of the backward through time.  dh_t = dhs[:, t+1] (+ carry, the W_hh^T dgh of step t+1, when non-NULL):
+//   dn = dh (1-z);  dnp = dn (1-n^2);  dzp = dh (h_{t-1} - n) z (1-z);  drp = dnp gh_n r (1-r)
+//   dgi_all[:, t] = (drp, dzp, dnp);  dgh_all[:, t] = (drp, dzp, dnp r);  dhs[:, t] += dh z   (direct path to h_{t-1})
+__global__ __launch_bounds__(256) void tgru_cell_bwd_kernel(float* dhs, const float* __restrict__ carry,
+                                                            const float* __restrict__ hs, const float* __restrict__ gates,
+                                                            float* __restrict__ dgi_all, float* __restrict__ dgh_all,
+                                                            int H, int T, int t, int SP, int S) {
+    const int s4 = SP / 4;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)H * s4) return;
+    const int j = (int)(i / s4), q = (int)(i % s4);
+    f32x4* dhs4 = (f32x4*)dhs;
+    const size_t hrow = (size_t)(T + 1) * s4;
+    f32x4 dh = dhs4[(size_t)j * hrow + (size_t)(t + 1) * s4 + q];
+    if (carry) {
+        const f32x4 cv = ((const f32x4*)carry)[(size_t)j * s4 + q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dh[e] += cv[e];
+    }
+    const f32x4 hp = ((const f32x4*)hs)[(size_t)j * hrow + (size_t)t * s4 + q];
+    const f32x4* g4 = (const f32x4*)gates;
+    const size_t plane = (size_t)H * T * s4;
+    const size_t o_ = ((size_t)j * T + t) * s4 + q;
+    const f32x4 r = g4[o_], z = g4[plane + o_], n = g4[2 * plane + o_], ghn = g4[3 * plane + o_];
+    f32x4 drp, dzp, dnp, dnr, dprev;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float d = (4 * q + e < S) ? dh[e] : 0.f;          // padded sequences carry no gradient
+        const float dn = d * (1.f - z[e]);
+        dnp[e] = dn * (1.f - n[e] * n[e]);
+        dzp[e] = d * (hp[e] - n[e]) * z[e] * (1.f - z[e]);
+        drp[e] = dnp[e] * ghn[e] * r[e] * (1.f - r[e]);
+        dnr[e] = dnp[e] * r[e];
+        dprev[e] = d * z[e];
+    }
+    f32x4* dgi4 = (f32x4*)dgi_all;
+    f32x4* dgh4 = (f32x4*)dgh_all;
+    const size_t grow = (size_t)T * s4;
+    const size_t g0 = (size_t)j * grow + (size_t)t * s4 + q;
+    dgi4[g0] = drp; dgi4[(size_t)H * grow + g0] = dzp; dgi4[(size_t)2 * H * grow + g0] = dnp;
+    dgh4[g0] = drp; dgh4[(size_t)H * grow + g0] = dzp; dgh4[(size_t)2 * H * grow + g0] = dnr;
+    f32x4 acc = dhs4[(size_t)j * hrow + (size_t)t * s4 + q];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += dprev[e];
+    dhs4[(size_t)j * hrow + (size_t)t * s4 + q] = acc;
+}
+
 // ---------------------------------------------------------------- BatchNorm statistics -> affine
 __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __restrict__ partials, int nparts, int C,
                                                               double count, const float* __restrict__ gamma,
@@ -349,6 +505,46 @@ extern "C" int trunet_gru_cell(const float* gi, const float* gh, const float* h,
     const size_t R4 = (size_t)L * NP / 4;
     const size_t n = (size_t)H * R4;
     hipLaunchKernelGGL(gru_cell_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ST, gi, gh, h, h_new, H, R4);
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_to_seq_major(const float* x, float* y, const float* scale, const float* shift, int relu, int C,
+                                   int Lf, int T, int B, int NP, int SP, void* stream) {
+    if (!x || !y || C <= 0 || Lf <= 0 || T <= 0 || B <= 0 || (size_t)B * T > (size_t)NP || B * Lf > SP) return TRUNET_EINVAL;
+    if (hipMemsetAsync(y, 0, (size_t)C * T * SP * sizeof(float), ST) != hipSuccess) return TRUNET_ELAUNCH;
+    hipLaunchKernelGGL(to_seq_major_kernel, dim3((T + 31) / 32, (B + 31) / 32, C * Lf), dim3(32, 8), 0, ST, x, y, scale,
+                       shift, Lf, T, B, NP, SP, (scale && relu) ? 0.f : -3.0e38f);
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_from_seq_major_nparts(int Lf, int T, int B) { return ((T + 31) / 32) * ((B + 31) / 32) * Lf; }
+
+extern "C" int trunet_from_seq_major(const float* y, float* x, const float* zsrc, const float* scale, const float* shift,
+                                     const float* mean, float* partials, int C, int Lf, int T, int B, int NP, int SP,
+                                     void* stream) {
+    if (!x || !y || C <= 0 || Lf <= 0 || T <= 0 || B <= 0 || (size_t)B * T > (size_t)NP || B * Lf > SP) return TRUNET_EINVAL;
+    if (zsrc && (!scale || !shift || !mean || !partials)) return TRUNET_EINVAL;
+    hipLaunchKernelGGL(from_seq_major_kernel, dim3((T + 31) / 32, (B + 31) / 32, C * Lf), dim3(32, 8), 0, ST, y, x, zsrc,
+                       scale, shift, mean, partials, C, Lf, T, B, NP, SP);
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_tgru_cell_fwd(const float* gi_all, const float* gh, float* hs, float* gates, int H, int T, int t,
+                                    int SP, void* stream) {
+    if (!gi_all || !gh || !hs || H <= 0 || T <= 0 || t < 0 || t >= T || SP <= 0 || (SP % 4)) return TRUNET_EINVAL;
+    const size_t n = (size_t)H * (SP / 4);
+    hipLaunchKernelGGL(tgru_cell_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ST, gi_all, gh, hs, gates, H,
+                       T, t, SP);
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_tgru_cell_bwd(float* dhs, const float* carry, const float* hs, const float* gates, float* dgi_all,
+                                    float* dgh_all, int H, int T, int t, int SP, int S, void* stream) {
+    if (!dhs || !hs || !gates || !dgi_all || !dgh_all || H <= 0 || T <= 0 || t < 0 || t >= T || SP <= 0 || (SP % 4))
+        return TRUNET_EINVAL;
+    const size_t n = (size_t)H * (SP / 4);
+    hipLaunchKernelGGL(tgru_cell_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ST, dhs, carry, hs, gates,
+                       dgi_all, dgh_all, H, T, t, SP, S);
     return trunet_launch_status();
 }
 

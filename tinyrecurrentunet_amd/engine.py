@@ -194,6 +194,120 @@ class TRUNetEngine:
         check(L.lib().trunet_conv_gemm(a, L.stream()), "conv_gemm")
         return nparts
 
+    def _gemm_args(self, *, N, NP, P, M, out, out_L, W, ldw_m, ldw_c, segs, bias=None, p_begin=0):
+        """GemmArgs for a launch that is repeated with a changing segment offset (the TGRU time loop)."""
+        a = GemmArgs()
+        a.NP, a.N, a.P, a.p_begin = NP, N, P, p_begin
+        a.M, a.m_out_off, a.out_L, a.out_pos_off = M, 0, out_L, 0
+        a.ldw_m, a.ldw_c, a.w_m_off = ldw_m, ldw_c, 0
+        a.nseg = len(segs)
+        for i, sg in enumerate(segs):
+            a.seg[i] = sg
+        a.out, a.W = ptr(out), ptr(W)
+        a.epi = 0
+        if bias is not None:
+            a.epi |= EPI_BIAS
+            a.bias = ptr(bias)
+        return a
+
+    # ------------------------------------------------------------------ TGRU as a trained layer (use_tgru)
+    def _tgru_seq_fwd(self, w, cur, N, NP, T, training, acts):
+        """GRUBlock(64, 128, 64) of network.py:150 over TIME, between FGRU and the decoder (docs/net.jpg; SURVEY 8f
+        rank 1): every (utterance, frequency position) is a sequence of T frames.  Sequence-major tensors [C][T][SP];
+        the input projection, the block's pointwise conv and all weight gradients are single launches of the existing
+        GEMM kernels, the recurrence itself is a host loop of (W_hh h GEMM, cell) pairs -- correct first; a persistent
+        recurrent kernel is the next step."""
+        lib, st = L.lib(), L.stream()
+        blk = self.net.TGRU
+        gru = blk.GRU
+        Hh, Lf, C = gru.hidden_size, cur.L, cur.C
+        if gru.bidirectional or gru.input_size != C or T <= 0 or N % T:
+            raise L.TrunetHipError("use_tgru needs N = B*T frames (got N=%d, T=%d) and the GRUBlock(64,128,64) of "
+                                   "network.py:150" % (N, T))
+        B = N // T
+        S = B * Lf
+        SP = ceil_to(S, FRAME_PAD)
+        xs = w.get("tg.xs", (C, T, SP))
+        check(lib.trunet_to_seq_major(ptr(cur.t), ptr(xs), ptr(cur.bn.scale), ptr(cur.bn.shift), 1, C, Lf, T, B, NP, SP,
+                                      st), "to_seq_major")
+        gi = w.get("tg.gi", (3 * Hh, T, SP))
+        self._gemm(w, N=S, NP=SP, P=T, M=3 * Hh, out=gi, out_L=T, W=gru.weight_ih_l0.data, ldw_m=C, ldw_c=1,
+                   segs=[make_seg(xs, C, T)], bias=gru.bias_ih_l0.data)
+        hs = w.get("tg.hs", (Hh, T + 1, SP))
+        hs[:, 0].zero_()                                           # h_{-1} = 0 like nn.GRU
+        gates = w.get("tg.gates", (4, Hh, T, SP)) if training else None
+        gh = w.get("tg.gh", (3 * Hh, 1, SP))
+        a = self._gemm_args(N=S, NP=SP, P=1, M=3 * Hh, out=gh, out_L=1, W=gru.weight_hh_l0.data, ldw_m=Hh, ldw_c=1,
+                            segs=[make_seg(hs, Hh, T + 1)], bias=gru.bias_hh_l0.data)
+        for t in range(T):
+            a.seg[0].pos_off = t                                   # h_{t-1} sits at position t
+            check(lib.trunet_conv_gemm(a, st), "conv_gemm")
+            check(lib.trunet_tgru_cell_fwd(ptr(gi), ptr(gh), ptr(hs), ptr(gates), Hh, T, t, SP, st), "tgru_cell_fwd")
+        # the block's Conv1d(128 -> 64, k=1) + BatchNorm over (B*16, 64, T), then back to frames-last
+        conv, bn = blk.conv[0], blk.conv[1]
+        zc = w.get("tg.zc", (conv.out_channels, T, SP))
+        nparts = self._gemm(w, N=S, NP=SP, P=T, M=conv.out_channels, out=zc, out_L=T, W=conv.weight.data,
+                            ldw_m=Hh, ldw_c=1, segs=[make_seg(hs, Hh, T + 1, pos_off=1)], bias=conv.bias.data,
+                            stats=(conv.out_channels if training else None))
+        stt = self._bn_fwd(w, "tgru", bn, conv.out_channels, S * T, nparts, training)
+        zt = w.get("z:tgru", (conv.out_channels, Lf, NP), zero=True)
+        check(lib.trunet_from_seq_major(ptr(zc), ptr(zt), None, None, None, None, None, conv.out_channels, Lf, T, B, NP,
+                                        SP, st), "from_seq_major")
+        acts["tgru.ctx"] = dict(xs=xs, gi=gi, hs=hs, gates=gates, zc=zc, S=S, SP=SP, T=T, B=B)
+        return Act(zt, conv.out_channels, Lf, stt)
+
+    def _tgru_seq_bwd(self, w, acts, dy, bn, N, NP, grads):
+        """Backward of _tgru_seq_fwd: dy [64][16][NP] is the (ReLU-masked) gradient of the block's BatchNorm output,
+        bn that BatchNorm's state.  Returns the gradient w.r.t. FGRU's raw conv output (masked, with its statistics)."""
+        lib, st = L.lib(), L.stream()
+        c = acts["tgru.ctx"]
+        xs, gi, hs, gates, zc, S, SP, T, B = (c[k] for k in ("xs", "gi", "hs", "gates", "zc", "S", "SP", "T", "B"))
+        blk = self.net.TGRU
+        gru, conv = blk.GRU, blk.conv[0]
+        Hh, Cc = gru.hidden_size, conv.out_channels
+        src = acts["fgru"]
+        Lf, C = src.L, src.C
+        dys = w.get("tg.dys", (Cc, T, SP))
+        check(lib.trunet_to_seq_major(ptr(dy), ptr(dys), None, None, 0, Cc, Lf, T, B, NP, SP, st), "to_seq_major")
+        # pointwise conv + BatchNorm backward (fused): weight/bias gradient and dL/dh_t at position t+1
+        dhs = w.get("tg.dhs", (Hh, T + 1, SP))
+        dhs[:, 0].zero_()
+        self._pw_bwd(w, N=S, NP=SP, P=T, M=Cc, dz=dys, dz1=zc, dz_bn=bn, W=conv.weight, bias=conv.bias,
+                     segs=[make_seg(hs, Hh, T + 1, pos_off=1)], outs=[dict(out=dhs)], grads=grads)
+        # backward through time
+        dgi = w.get("tg.dgi", (3 * Hh, T, SP))
+        dgh = w.get("tg.dgh", (3 * Hh, T, SP))
+        cg = w.get("tg.carry", (Hh, 1, SP))
+        a = self._gemm_args(N=S, NP=SP, P=1, M=Hh, out=cg, out_L=1, W=gru.weight_hh_l0.data, ldw_m=1, ldw_c=Hh,
+                            segs=[make_seg(dgh, 3 * Hh, T)])
+        carry = None
+        for t in range(T - 1, -1, -1):
+            check(lib.trunet_tgru_cell_bwd(ptr(dhs), ptr(carry), ptr(hs), ptr(gates), ptr(dgi), ptr(dgh), Hh, T, t, SP,
+                                           S, st), "tgru_cell_bwd")
+            if t > 0:
+                a.seg[0].pos_off = t                               # W_hh^T dgh_t -> gradient of h_{t-1}
+                check(lib.trunet_conv_gemm(a, st), "conv_gemm")
+                carry = cg
+        # weight gradients over all time steps at once (384 rows of dz in three launches of 128)
+        for g in range(3):
+            self._wgrad(w, N=S, NP=SP, P=T, M=Hh, dz=dgh, dz_L=T, dz_bn=None, a_m_off=g * Hh, w_m_off=g * Hh,
+                        W=gru.weight_hh_l0, ldw_m=Hh, ldw_c=1, segs=[make_seg(hs, Hh, T + 1)], grads=grads,
+                        bias=gru.bias_hh_l0, b_off=g * Hh)
+            self._wgrad(w, N=S, NP=SP, P=T, M=Hh, dz=dgi, dz_L=T, dz_bn=None, a_m_off=g * Hh, w_m_off=g * Hh,
+                        W=gru.weight_ih_l0, ldw_m=C, ldw_c=1, segs=[make_seg(xs, C, T)], grads=grads,
+                        bias=gru.bias_ih_l0, b_off=g * Hh)
+        # data gradient of the input projection, back to frames-last through FGRU's BatchNorm+ReLU
+        dxs = w.get("tg.dxs", (C, T, SP))
+        self._gemm(w, N=S, NP=SP, P=T, M=C, out=dxs, out_L=T, W=gru.weight_ih_l0.data, ldw_m=1, ldw_c=C,
+                   segs=[make_seg(dgi, 3 * Hh, T)])
+        dyf = w.get("dy:fgru", (C, Lf, NP), zero=True)
+        nparts = lib.trunet_from_seq_major_nparts(Lf, T, B)
+        part = w.flat("tg.partials", nparts * C * 2)
+        check(lib.trunet_from_seq_major(ptr(dxs), ptr(dyf), ptr(src.t), ptr(src.bn.scale), ptr(src.bn.shift),
+                                        ptr(src.bn.mean), ptr(part), C, Lf, T, B, NP, SP, st), "from_seq_major")
+        self._bn_bwd(w, src.bn, nparts, grads, part_name="tg.partials")
+        return dyf, src.t, src.bn
+
     def _bn_fwd(self, w, name, module, C, count, nparts, training):
         st = w.bn(name, C)
         st.module, st.count = module, float(count)
@@ -387,7 +501,7 @@ class TRUNetEngine:
         state.steps += 1
         return self._pw(w, "tgru", [Act(state.h, Hh, Lg)], blk.conv[0], blk.conv[1], N, NP, False)
 
-    def forward(self, x, training, tgru_state=None):
+    def forward(self, x, training, tgru_state=None, tgru_T=None):
         net = self.net
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[2] == F_BINS
         x = x.contiguous()
@@ -419,6 +533,8 @@ class TRUNetEngine:
 
         if tgru_state is not None:
             cur = acts["tgru"] = self._tgru_step(w, cur, tgru_state, N, NP)
+        elif tgru_T is not None:
+            cur = acts["tgru"] = self._tgru_seq_fwd(w, cur, N, NP, tgru_T, training, acts)
 
         seq = net.decoder[0].FirstTrCNN
         cur = acts["dec0.pw"] = self._pw(w, "dec0.pw", [cur], seq[0], seq[1], N, NP, training)
@@ -604,13 +720,13 @@ class TRUNetEngine:
                 left = (skip.L - x1.L) // 2
                 srcs = [x1.seg(pos_off=-left, woff=0), skip.seg(woff=x1.C)]
             else:
-                x1 = acts["fgru"]
+                x1 = acts.get("tgru", acts["fgru"])
                 skip, left = None, 0
                 srcs = [x1.seg()]
             Lp = a_pw.L
             p0, p1 = max(0, left), min(Lp, x1.L + left)
-            dy_x1 = w.get("dy:" + ("dec%d" % (i - 1) if i > 0 else "fgru"), (x1.C, x1.L, NP),
-                          zero=(p1 - p0 < x1.L))
+            dy_x1 = w.get("dy:" + ("dec%d" % (i - 1) if i > 0 else ("tgru" if "tgru" in acts else "fgru")),
+                          (x1.C, x1.L, NP), zero=(p1 - p0 < x1.L))
             g_skip = w.get("dy:enc%d" % (5 - i), (skip.C, skip.L, NP)) if skip is not None else None
             if FUSED_PWBWD and pw.out_channels % 32 == 0:
                 outs = [dict(out=dy_x1, src=x1)] + ([dict(out=g_skip)] if skip is not None else [])
@@ -630,6 +746,9 @@ class TRUNetEngine:
                 self._gemm(w, N=N, NP=NP, P=Lp, M=skip.C, out=g_skip, out_L=skip.L, W=pw.weight.data, ldw_m=1,
                            ldw_c=Kin, w_m_off=x1.C, segs=[dz_segs(dy, z, bn, pw.out_channels, Lp)])
             dy, z, bn = dy_x1, x1.t, x1.bn
+
+        if "tgru.ctx" in acts:            # time-recurrent block between FGRU and the decoder
+            dy, z, bn = self._tgru_seq_bwd(w, acts, dy, bn, N, NP, grads)
 
         # -------- FGRU.conv (pw over hout)
         conv = net.FGRU.conv[0]

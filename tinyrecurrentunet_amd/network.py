@@ -139,8 +139,8 @@ class _TRUNetFn(torch.autograd.Function):
     carry no gradient in the reference either, util.py:214-218)."""
 
     @staticmethod
-    def forward(ctx, x, engine, training, *params):
-        out, ectx = engine.forward(x, training)
+    def forward(ctx, x, engine, training, tgru_T, *params):
+        out, ectx = engine.forward(x, training, tgru_T=tgru_T)
         ctx.engine, ctx.ectx, ctx.params = engine, ectx, params
         ctx.training = training
         return out
@@ -151,7 +151,7 @@ class _TRUNetFn(torch.autograd.Function):
             raise _lib.TrunetHipError("backward through TRUNet in eval() mode is not supported "
                                       "(BatchNorm running statistics); call net.train()")
         grads = ctx.engine.backward(ctx.ectx, gout)
-        return (None, None, None) + tuple(grads.get(p) for p in ctx.params)
+        return (None, None, None, None) + tuple(grads.get(p) for p in ctx.params)
 
 
 class TRUNet(nn.Module):
@@ -162,8 +162,11 @@ class TRUNet(nn.Module):
     registered for checkpoint parity and not executed (R4)."""
 
     def __init__(self, input_size=3, channels_input=64, channels_output=3, channels_hidden=128,
-                 kernel_sizes=(5, 3), strides=(2, 1), tr_channels_input=192):
+                 kernel_sizes=(5, 3), strides=(2, 1), tr_channels_input=192, use_tgru=False):
         super().__init__()
+        # use_tgru (extension, default = the reference as written, R4): run the TGRU block over time between FGRU and
+        # the decoder as drawn in docs/net.jpg; forward then needs frames_per_seq = T (N = B*T frames)
+        self.use_tgru = bool(use_tgru)
         self.encoder = nn.ModuleList([
             StandardConv1d(input_size, 64, 5, 2),
             DepthwiseSeparableConv1d(64, 128, 3, 1),
@@ -200,16 +203,21 @@ class TRUNet(nn.Module):
         return out, state
 
     def _active_params(self):
-        return [p for n, p in self.named_parameters() if not n.startswith("TGRU.")]
+        return [p for n, p in self.named_parameters() if self.use_tgru or not n.startswith("TGRU.")]
 
-    def forward(self, x):
+    def forward(self, x, frames_per_seq=None):
         _need_gpu(x)
         if self._engine is None:
             object.__setattr__(self, "_engine", TRUNetEngine(self))
+        T = None
+        if self.use_tgru:
+            if frames_per_seq is None:
+                raise _lib.TrunetHipError("use_tgru: pass frames_per_seq = T (x holds B utterances of T frames each)")
+            T = int(frames_per_seq)
         params = self._active_params()
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
-            return _TRUNetFn.apply(x, self._engine, self.training, *params)
-        out, _ = self._engine.forward(x, self.training)
+            return _TRUNetFn.apply(x, self._engine, self.training, T, *params)
+        out, _ = self._engine.forward(x, self.training, tgru_T=T)
         return out
 
 

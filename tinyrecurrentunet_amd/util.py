@@ -78,7 +78,8 @@ def loss_fn(net, X, ell_p, ell_p_lambda, stft_lambda, mrstftloss, pcen=None, **k
         pcen = net.encoder[0].StandardConv1d[0].in_channels == 4
     feats = ds.stft_features(noisy, pcen=pcen)
     T = feats.shape[0] // noisy.shape[0]
-    out = net(feats)
+    # use_tgru (extension): the time-recurrent block needs to know where utterances begin
+    out = net(feats, frames_per_seq=T) if getattr(net, "use_tgru", False) else net(feats)
     den, l1 = denoise(out, clean, T)
     l1 = torch.abs(l1)
     loss = l1 * ell_p_lambda
