@@ -226,6 +226,15 @@ int trunet_from_seq_major(const float* y, float* x, const float* zsrc, const flo
  * gates [4][H][T][SP] = r, z, n, gh_n (NULL in eval).  bwd: dhs [H][T+1][SP] holds dL/dh_t at position t+1 and receives
  * the direct term dh_t z_t at position t; carry [H][SP] = W_hh^T dgh_{t+1} (NULL at t = T-1); writes dgi_all / dgh_all
  * [3H][T][SP] rows of step t; sequences s >= S carry no gradient. */
+/* the same T forward steps as one persistent launch (H = 128): W_hh in registers, h through LDS; writes hs positions
+ * 1..T (position 0 must hold h_{-1} = 0) and, when non-NULL, the gates.  Here gi_all must already include
+ * b_ih + (b_hr, b_hz, 0) and b_hn points at the last H entries of b_hh (only b_hn sits inside r * (W_hn h + b_hn)). */
+int trunet_tgru_rec_fwd(const float* gi_all, const float* w_hh, const float* b_hn, float* hs, float* gates, int H, int T,
+                        int SP, void* stream);
+/* the T backward steps as one persistent launch (H = 128): reads dhs positions 1..T (dL/dh_t from the block's conv),
+ * hs, gates; writes dgi_all / dgh_all [3H][T][SP]; the carried gradient stays in registers (dhs is not modified). */
+int trunet_tgru_rec_bwd(const float* dhs, const float* hs, const float* gates, const float* w_hh, float* dgi_all,
+                        float* dgh_all, int H, int T, int SP, int S, void* stream);
 int trunet_tgru_cell_fwd(const float* gi_all, const float* gh, float* hs, float* gates, int H, int T, int t, int SP,
                          void* stream);
 int trunet_tgru_cell_bwd(float* dhs, const float* carry, const float* hs, const float* gates, float* dgi_all,

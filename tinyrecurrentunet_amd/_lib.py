@@ -103,6 +103,8 @@ def _declare(L):
         "trunet_from_seq_major_nparts": [i, i, i],
         "trunet_from_seq_major": [p, p, p, p, p, p, p, i, i, i, i, i, i, p],
         "trunet_tgru_cell_fwd": [p, p, p, p, i, i, i, i, p],
+        "trunet_tgru_rec_fwd": [p, p, p, p, p, i, i, i, p],
+        "trunet_tgru_rec_bwd": [p, p, p, p, p, p, i, i, i, i, p],
         "trunet_tgru_cell_bwd": [p, p, p, p, p, p, i, i, i, i, i, p],
         "trunet_adamw": [p, p, p, p, i64, f, f, f, f, f, i, p],
         "trunet_sumsq": [p, i64, p, p],

@@ -202,3 +202,269 @@ extern "C" int trunet_gru_bwd(const float* dhout, const float* hout, const float
                        w_hh_rev, dgi, dghn, L, NP, N);
     return trunet_launch_status();
 }
+
+// =====================================================================================
+// TGRU (network.py:150 used over time): persistent recurrence over T time steps on sequence-major
+// tensors [C][T][SP].  H = 128 hidden units, unidirectional.  A workgroup owns 32 sequences (columns) for all T steps:
+// W_hh (384 x 128 floats = 192 KiB) lives in the registers of its 8 waves as MFMA A fragments -- wave (ut, kh) holds
+// the three gates of unit tile ut (32 units) for K half kh (64 of the 128 h rows): 96 VGPRs -- h_{t-1} goes through
+// LDS (B operand), the K halves are combined through LDS once per step, and the kh = 0 waves run the gate math on the
+// MFMA C layout exactly like gru_fwd_kernel.  Replaces a host loop of T (GEMM, cell) launch pairs.
+// =====================================================================================
+namespace {
+
+constexpr int TH = 128;    // hidden units
+constexpr int TS = 32;     // sequences per workgroup
+
+// global access as uniform row base (SGPR pair) + per-lane byte offset: sixteen rows x eight tensors of per-lane 64-bit
+// addresses would not fit the register budget next to W_hh.  The loaded value is usable after tg_fence16.
+__device__ __forceinline__ void tg_load(float& v, const float* sbase, int voff) {
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void tg_store(float* sbase, int voff, float v) {
+    asm volatile("global_store_dword %0, %1, %2" :: "v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+#define TG_FENCE16(a, wait)                                                                                             \
+    asm volatile(wait : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),   \
+                 "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])     \
+                 :: "memory")
+
+__global__ __launch_bounds__(512, 2) void tgru_rec_fwd_kernel(const float* __restrict__ gi_all,
+                                                              const float* __restrict__ whh,
+                                                              const float* __restrict__ bhn, float* __restrict__ hs,
+                                                              float* __restrict__ gates, int T, int SP) {
+    __shared__ __attribute__((aligned(16))) float hbuf[2][TH][TS];          // h_{t-1} / h_t, [unit][sequence]
+    __shared__ __attribute__((aligned(16))) float part[4][3][16][64];       // K-half-1 partial sums per unit tile
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ut = wave & 3, kh = wave >> 2;
+    const int hh = lane >> 5, c = lane & 31;
+    const int s0 = blockIdx.x * TS;
+
+    // A fragments: A[g][kk] = W_hh[g*128 + 32*ut + c][64*kh + 2*kk + hh]
+    float A[3][32];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) A[g][kk] = whh[(size_t)(g * TH + 32 * ut + c) * TH + 64 * kh + 2 * kk + hh];
+    // gi_all already carries b_ih + (b_hr, b_hz, 0): only b_hn must stay inside r * (W_hn h + b_hn)
+    float bias_n[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int u = 32 * ut + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        bias_n[r] = (kh == 0) ? bhn[u] : 0.f;
+    }
+    for (int i = tid; i < TH * TS; i += 512) (&hbuf[0][0][0])[i] = 0.f;      // h_{-1} = 0
+    float hprev[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hprev[r] = 0.f;
+    __syncthreads();
+
+    const size_t grow = (size_t)T * SP;              // row stride of gi_all / gates planes
+    const size_t hrow = (size_t)(T + 1) * SP;        // row stride of hs
+    const int voff_g = (int)((4 * hh * grow + c) * sizeof(float));     // per-lane part of a gi / gates address
+    const int voff_h = (int)((4 * hh * hrow + c) * sizeof(float));     // per-lane part of an hs address
+    for (int t = 0; t < T; ++t) {
+        const int cur = t & 1;
+        float a0[16], a1[16], gin[16];
+        f32x16 acc[3];
+        // kh = 0 waves seed the accumulators with gi (+ folded biases); gi_n stays aside, gh_n accumulates on b_hn alone
+        if (kh == 0) {
+            const float* gb = gi_all + (size_t)(32 * ut) * grow + (size_t)t * SP + s0;      // uniform
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const size_t ro = (size_t)((r & 3) + 8 * (r >> 2)) * grow;
+                tg_load(a0[r], gb + ro, voff_g);
+                tg_load(a1[r], gb + (size_t)TH * grow + ro, voff_g);
+                tg_load(gin[r], gb + (size_t)2 * TH * grow + ro, voff_g);
+            }
+            TG_FENCE16(a0, "s_waitcnt vmcnt(0)");
+            TG_FENCE16(a1, "");
+            TG_FENCE16(gin, "");
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[0][r] = a0[r]; acc[1][r] = a1[r]; acc[2][r] = bias_n[r]; }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+        }
+        if (t > 0) {
+            const float* hb = &hbuf[cur][64 * kh][0];
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) {
+                const float b = hb[(2 * kk + hh) * TS + c];
+#pragma unroll
+                for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g][kk], b, acc[g], 0, 0, 0);
+            }
+        }
+        if (kh == 1) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) part[ut][g][r][lane] = acc[g][r];
+        }
+        __syncthreads();
+        if (kh == 0) {
+            float* hw = &hbuf[cur ^ 1][0][0];
+            float* hsb = hs + (size_t)(32 * ut) * hrow + (size_t)(t + 1) * SP + s0;        // uniform
+            float* gtb = gates ? gates + (size_t)(32 * ut) * grow + (size_t)t * SP + s0 : nullptr;
+            const size_t plane = (size_t)TH * grow;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = (r & 3) + 8 * (r >> 2);
+                const int u = 32 * ut + ml + 4 * hh;
+                const float ar = acc[0][r] + part[ut][0][r][lane];
+                const float az = acc[1][r] + part[ut][1][r][lane];
+                const float gh = acc[2][r] + part[ut][2][r][lane];
+                const float rr = sigmoidf_(ar);
+                const float zz = sigmoidf_(az);
+                const float nn = tanhf(fmaf(rr, gh, gin[r]));
+                const float hn = fmaf(zz, hprev[r] - nn, nn);
+                hprev[r] = hn;
+                hw[u * TS + c] = hn;
+                tg_store(hsb + (size_t)ml * hrow, voff_h, hn);
+                if (gates) {
+                    float* gr = gtb + (size_t)ml * grow;
+                    tg_store(gr, voff_g, rr);
+                    tg_store(gr + plane, voff_g, zz);
+                    tg_store(gr + 2 * plane, voff_g, nn);
+                    tg_store(gr + 3 * plane, voff_g, gh);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Backward through time of the same recurrence, one persistent launch.  Per step t (T-1 .. 0), for the 32 sequences of the
+// workgroup:  dh = dhs[:, t+1] + carry;  (drp, dzp, dnp) as in tgru_cell_bwd_kernel;  dgi_all / dgh_all rows of step t;
+// carry' = dh z + W_hh^T dgh.  Wave (ut, kh) keeps W_hh^T[unit tile ut][K half kh of the 384 gate rows] as A fragments
+// (96 VGPRs); dgh goes through LDS as the B operand; the kh = 0 waves own `carry` on the MFMA C layout and run the
+// elementwise phase there.  The last step leaves dL/dh_{-1} unused.
+__global__ __launch_bounds__(512, 2) void tgru_rec_bwd_kernel(const float* __restrict__ dhs, const float* __restrict__ hs,
+                                                              const float* __restrict__ gates,
+                                                              const float* __restrict__ whh, float* __restrict__ dgi_all,
+                                                              float* __restrict__ dgh_all, int T, int SP, int S) {
+    __shared__ __attribute__((aligned(16))) float dgb[3 * TH][TS];          // dgh of the current step, [gate row][sequence]
+    __shared__ __attribute__((aligned(16))) float part[4][16][64];          // K-half-1 partial sums per unit tile
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ut = wave & 3, kh = wave >> 2;
+    const int hh = lane >> 5, c = lane & 31;
+    const int s0 = blockIdx.x * TS;
+
+    // A fragments of W_hh^T: A[kk] = W_hh[192*kh + 2*kk + hh][32*ut + c]
+    float A[96];
+#pragma unroll
+    for (int kk = 0; kk < 96; ++kk) A[kk] = whh[(size_t)(192 * kh + 2 * kk + hh) * TH + 32 * ut + c];
+    float carry[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) carry[r] = 0.f;
+    const size_t grow = (size_t)T * SP;
+    const size_t hrow = (size_t)(T + 1) * SP;
+    const size_t plane = (size_t)TH * grow;
+    const int voff_g = (int)((4 * hh * grow + c) * sizeof(float));
+    const int voff_h = (int)((4 * hh * hrow + c) * sizeof(float));
+    const bool live = s0 + c < S;                    // padded sequences carry no gradient
+
+    for (int t = T - 1; t >= 0; --t) {
+        float dzd[16];                               // dh z: the direct path into h_{t-1}
+        if (kh == 0) {
+            const float* dhb = dhs + (size_t)(32 * ut) * hrow + (size_t)(t + 1) * SP + s0;     // uniform bases
+            const float* hpb = hs + (size_t)(32 * ut) * hrow + (size_t)t * SP + s0;
+            const float* gtb = gates + (size_t)(32 * ut) * grow + (size_t)t * SP + s0;
+            float* gib = dgi_all + (size_t)(32 * ut) * grow + (size_t)t * SP + s0;
+            float* ghb = dgh_all + (size_t)(32 * ut) * grow + (size_t)t * SP + s0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {            // four rows at a time: 24 loads in flight
+                float v[4][6];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 4 * q + i;
+                    const size_t mg = (size_t)((r & 3) + 8 * (r >> 2)) * grow;
+                    const size_t mh = (size_t)((r & 3) + 8 * (r >> 2)) * hrow;
+                    tg_load(v[i][0], dhb + mh, voff_h);
+                    tg_load(v[i][1], hpb + mh, voff_h);
+                    tg_load(v[i][2], gtb + mg, voff_g);
+                    tg_load(v[i][3], gtb + plane + mg, voff_g);
+                    tg_load(v[i][4], gtb + 2 * plane + mg, voff_g);
+                    tg_load(v[i][5], gtb + 3 * plane + mg, voff_g);
+                }
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[0][2]), "+v"(v[0][3]), "+v"(v[0][4]), "+v"(v[0][5]),
+                               "+v"(v[1][0]), "+v"(v[1][1]), "+v"(v[1][2]), "+v"(v[1][3]), "+v"(v[1][4]), "+v"(v[1][5]),
+                               "+v"(v[2][0]), "+v"(v[2][1]), "+v"(v[2][2]), "+v"(v[2][3]), "+v"(v[2][4]), "+v"(v[2][5]),
+                               "+v"(v[3][0]), "+v"(v[3][1]), "+v"(v[3][2]), "+v"(v[3][3]), "+v"(v[3][4]), "+v"(v[3][5])
+                             :: "memory");
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 4 * q + i;
+                    const int ml = (r & 3) + 8 * (r >> 2);
+                    const int u = 32 * ut + ml + 4 * hh;
+                    const float d = live ? v[i][0] + carry[r] : 0.f;
+                    const float hp = v[i][1], rr = v[i][2], zz = v[i][3], nn = v[i][4], ghn = v[i][5];
+                    const float dn = d * (1.f - zz);
+                    const float dnp = dn * (1.f - nn * nn);
+                    const float dzp = d * (hp - nn) * zz * (1.f - zz);
+                    const float drp = dnp * ghn * rr * (1.f - rr);
+                    const float dnr = dnp * rr;
+                    dzd[r] = d * zz;
+                    dgb[u][c] = drp;
+                    dgb[TH + u][c] = dzp;
+                    dgb[2 * TH + u][c] = dnr;
+                    const size_t mg = (size_t)ml * grow;
+                    tg_store(gib + mg, voff_g, drp);
+                    tg_store(gib + (size_t)TH * grow + mg, voff_g, dzp);
+                    tg_store(gib + (size_t)2 * TH * grow + mg, voff_g, dnp);
+                    tg_store(ghb + mg, voff_g, drp);
+                    tg_store(ghb + (size_t)TH * grow + mg, voff_g, dzp);
+                    tg_store(ghb + (size_t)2 * TH * grow + mg, voff_g, dnr);
+                }
+            }
+        }
+        __syncthreads();                              // dgh of step t is in LDS
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if (t > 0) {                                  // the gradient of h_{-1} is not needed
+            const float* db = &dgb[192 * kh][0];
+#pragma unroll
+            for (int kk = 0; kk < 96; ++kk) {
+                const float b = db[(2 * kk + hh) * TS + c];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[kk], b, acc, 0, 0, 0);
+            }
+            if (kh == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) part[ut][r][lane] = acc[r];
+            }
+        }
+        __syncthreads();                              // partial sums visible; every read of dgb is done
+        if (kh == 0 && t > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) carry[r] = dzd[r] + acc[r] + part[ut][r][lane];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int trunet_tgru_rec_bwd(const float* dhs, const float* hs, const float* gates, const float* w_hh, float* dgi_all,
+                                   float* dgh_all, int H, int T, int SP, int S, void* stream) {
+    if (!dhs || !hs || !gates || !w_hh || !dgi_all || !dgh_all || T <= 0 || SP <= 0 || (SP % TS) || S > SP) return TRUNET_EINVAL;
+    if (H != TH) return TRUNET_ENOTSUP;
+    hipLaunchKernelGGL(tgru_rec_bwd_kernel, dim3(SP / TS), dim3(512), 0, (hipStream_t)stream, dhs, hs, gates, w_hh, dgi_all,
+                       dgh_all, T, SP, S);
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_tgru_rec_fwd(const float* gi_all, const float* w_hh, const float* b_hn, float* hs, float* gates,
+                                   int H, int T, int SP, void* stream) {
+    if (!gi_all || !w_hh || !b_hn || !hs || T <= 0 || SP <= 0 || (SP % TS)) return TRUNET_EINVAL;
+    if (H != TH) return TRUNET_ENOTSUP;
+    hipLaunchKernelGGL(tgru_rec_fwd_kernel, dim3(SP / TS), dim3(512), 0, (hipStream_t)stream, gi_all, w_hh, b_hn, hs, gates,
+                       T, SP);
+    return trunet_launch_status();
+}

@@ -28,6 +28,9 @@ BN_MOM = 0.1
 # trunet_conv_wgrad + trunet_conv_gemm; TRUNET_FUSED_PWBWD=0 keeps the separate launches (A/B measurements).
 FUSED_PWBWD = os.environ.get("TRUNET_FUSED_PWBWD", "1") != "0"
 
+# TGRU time loop as a host loop of (GEMM, cell) launch pairs instead of the persistent kernels (A/B, other H)
+TGRU_LOOP = os.environ.get("TRUNET_TGRU_LOOP", "0") == "1"
+
 # bench.py sets this to a dict to time kernels with HIP events on the launch stream:
 # PROFILE[kernel] = [(start_event, end_event, algorithmic_flops), ...]
 PROFILE = None
@@ -231,18 +234,30 @@ class TRUNetEngine:
         check(lib.trunet_to_seq_major(ptr(cur.t), ptr(xs), ptr(cur.bn.scale), ptr(cur.bn.shift), 1, C, Lf, T, B, NP, SP,
                                       st), "to_seq_major")
         gi = w.get("tg.gi", (3 * Hh, T, SP))
+        persistent = Hh == 128 and not TGRU_LOOP
+        b_in = gru.bias_ih_l0.data
+        if persistent:      # the recurrent kernel wants b_hr, b_hz folded into the projection's bias (b_hn stays inside)
+            b_in = w.get("tg.bias", (3 * Hh,))
+            torch.add(gru.bias_ih_l0.data, gru.bias_hh_l0.data, out=b_in)
+            b_in[2 * Hh:].copy_(gru.bias_ih_l0.data[2 * Hh:])
         self._gemm(w, N=S, NP=SP, P=T, M=3 * Hh, out=gi, out_L=T, W=gru.weight_ih_l0.data, ldw_m=C, ldw_c=1,
-                   segs=[make_seg(xs, C, T)], bias=gru.bias_ih_l0.data)
+                   segs=[make_seg(xs, C, T)], bias=b_in)
         hs = w.get("tg.hs", (Hh, T + 1, SP))
         hs[:, 0].zero_()                                           # h_{-1} = 0 like nn.GRU
         gates = w.get("tg.gates", (4, Hh, T, SP)) if training else None
-        gh = w.get("tg.gh", (3 * Hh, 1, SP))
-        a = self._gemm_args(N=S, NP=SP, P=1, M=3 * Hh, out=gh, out_L=1, W=gru.weight_hh_l0.data, ldw_m=Hh, ldw_c=1,
-                            segs=[make_seg(hs, Hh, T + 1)], bias=gru.bias_hh_l0.data)
-        for t in range(T):
-            a.seg[0].pos_off = t                                   # h_{t-1} sits at position t
-            check(lib.trunet_conv_gemm(a, st), "conv_gemm")
-            check(lib.trunet_tgru_cell_fwd(ptr(gi), ptr(gh), ptr(hs), ptr(gates), Hh, T, t, SP, st), "tgru_cell_fwd")
+        if persistent:
+            # persistent recurrence: one launch for all T steps (W_hh in registers, h through LDS)
+            check(lib.trunet_tgru_rec_fwd(ptr(gi), ptr(gru.weight_hh_l0.data), ptr(gru.bias_hh_l0.data[2 * Hh:]),
+                                          ptr(hs), ptr(gates), Hh, T, SP, st), "tgru_rec_fwd")
+        else:
+            gh = w.get("tg.gh", (3 * Hh, 1, SP))
+            a = self._gemm_args(N=S, NP=SP, P=1, M=3 * Hh, out=gh, out_L=1, W=gru.weight_hh_l0.data, ldw_m=Hh,
+                                ldw_c=1, segs=[make_seg(hs, Hh, T + 1)], bias=gru.bias_hh_l0.data)
+            for t in range(T):
+                a.seg[0].pos_off = t                               # h_{t-1} sits at position t
+                check(lib.trunet_conv_gemm(a, st), "conv_gemm")
+                check(lib.trunet_tgru_cell_fwd(ptr(gi), ptr(gh), ptr(hs), ptr(gates), Hh, T, t, SP, st),
+                      "tgru_cell_fwd")
         # the block's Conv1d(128 -> 64, k=1) + BatchNorm over (B*16, 64, T), then back to frames-last
         conv, bn = blk.conv[0], blk.conv[1]
         zc = w.get("tg.zc", (conv.out_channels, T, SP))
@@ -277,17 +292,21 @@ class TRUNetEngine:
         # backward through time
         dgi = w.get("tg.dgi", (3 * Hh, T, SP))
         dgh = w.get("tg.dgh", (3 * Hh, T, SP))
-        cg = w.get("tg.carry", (Hh, 1, SP))
-        a = self._gemm_args(N=S, NP=SP, P=1, M=Hh, out=cg, out_L=1, W=gru.weight_hh_l0.data, ldw_m=1, ldw_c=Hh,
-                            segs=[make_seg(dgh, 3 * Hh, T)])
-        carry = None
-        for t in range(T - 1, -1, -1):
-            check(lib.trunet_tgru_cell_bwd(ptr(dhs), ptr(carry), ptr(hs), ptr(gates), ptr(dgi), ptr(dgh), Hh, T, t, SP,
-                                           S, st), "tgru_cell_bwd")
-            if t > 0:
-                a.seg[0].pos_off = t                               # W_hh^T dgh_t -> gradient of h_{t-1}
-                check(lib.trunet_conv_gemm(a, st), "conv_gemm")
-                carry = cg
+        if Hh == 128 and not TGRU_LOOP:
+            check(lib.trunet_tgru_rec_bwd(ptr(dhs), ptr(hs), ptr(gates), ptr(gru.weight_hh_l0.data), ptr(dgi), ptr(dgh),
+                                          Hh, T, SP, S, st), "tgru_rec_bwd")
+        else:
+            cg = w.get("tg.carry", (Hh, 1, SP))
+            a = self._gemm_args(N=S, NP=SP, P=1, M=Hh, out=cg, out_L=1, W=gru.weight_hh_l0.data, ldw_m=1, ldw_c=Hh,
+                                segs=[make_seg(dgh, 3 * Hh, T)])
+            carry = None
+            for t in range(T - 1, -1, -1):
+                check(lib.trunet_tgru_cell_bwd(ptr(dhs), ptr(carry), ptr(hs), ptr(gates), ptr(dgi), ptr(dgh), Hh, T, t,
+                                               SP, S, st), "tgru_cell_bwd")
+                if t > 0:
+                    a.seg[0].pos_off = t                           # W_hh^T dgh_t -> gradient of h_{t-1}
+                    check(lib.trunet_conv_gemm(a, st), "conv_gemm")
+                    carry = cg
         # weight gradients over all time steps at once (384 rows of dz in three launches of 128)
         for g in range(3):
             self._wgrad(w, N=S, NP=SP, P=T, M=Hh, dz=dgh, dz_L=T, dz_bn=None, a_m_off=g * Hh, w_m_off=g * Hh,
