@@ -265,7 +265,9 @@ class TRUNetEngine:
                             ldw_m=Hh, ldw_c=1, segs=[make_seg(hs, Hh, T + 1, pos_off=1)], bias=conv.bias.data,
                             stats=(conv.out_channels if training else None))
         stt = self._bn_fwd(w, "tgru", bn, conv.out_channels, S * T, nparts, training)
-        zt = w.get("z:tgru", (conv.out_channels, Lf, NP), zero=True)
+        zt = w.get("z:tgru", (conv.out_channels, Lf, NP))
+        if NP > N:
+            zt[:, :, N:].zero_()                                   # padding frames must stay finite (0 * NaN in the MFMAs)
         check(lib.trunet_from_seq_major(ptr(zc), ptr(zt), None, None, None, None, None, conv.out_channels, Lf, T, B, NP,
                                         SP, st), "from_seq_major")
         acts["tgru.ctx"] = dict(xs=xs, gi=gi, hs=hs, gates=gates, zc=zc, S=S, SP=SP, T=T, B=B)
@@ -319,7 +321,9 @@ class TRUNetEngine:
         dxs = w.get("tg.dxs", (C, T, SP))
         self._gemm(w, N=S, NP=SP, P=T, M=C, out=dxs, out_L=T, W=gru.weight_ih_l0.data, ldw_m=1, ldw_c=C,
                    segs=[make_seg(dgi, 3 * Hh, T)])
-        dyf = w.get("dy:fgru", (C, Lf, NP), zero=True)
+        dyf = w.get("dy:fgru", (C, Lf, NP))
+        if NP > N:
+            dyf[:, :, N:].zero_()
         nparts = lib.trunet_from_seq_major_nparts(Lf, T, B)
         part = w.flat("tg.partials", nparts * C * 2)
         check(lib.trunet_from_seq_major(ptr(dxs), ptr(dyf), ptr(src.t), ptr(src.bn.scale), ptr(src.bn.shift),
@@ -745,7 +749,13 @@ class TRUNetEngine:
             Lp = a_pw.L
             p0, p1 = max(0, left), min(Lp, x1.L + left)
             dy_x1 = w.get("dy:" + ("dec%d" % (i - 1) if i > 0 else ("tgru" if "tgru" in acts else "fgru")),
-                          (x1.C, x1.L, NP), zero=(p1 - p0 < x1.L))
+                          (x1.C, x1.L, NP))
+            if p1 - p0 < x1.L:          # cropped positions of x1 (network.py:96-97 with a negative pad) get no gradient
+                q0, q1 = p0 - left, p1 - left
+                if q0 > 0:
+                    dy_x1[:, :q0].zero_()
+                if q1 < x1.L:
+                    dy_x1[:, q1:].zero_()
             g_skip = w.get("dy:enc%d" % (5 - i), (skip.C, skip.L, NP)) if skip is not None else None
             if FUSED_PWBWD and pw.out_channels % 32 == 0:
                 outs = [dict(out=dy_x1, src=x1)] + ([dict(out=g_skip)] if skip is not None else [])
