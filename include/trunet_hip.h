@@ -127,7 +127,8 @@ int trunet_conv_wgrad(const trunet_wgrad_args* h_args, void* stream);
  * with e0 = seg.c0, e1 = seg.c1 of the segment (1, 0 for TRUNET_PRO_NONE), plus the BatchNorm-backward statistics
  * sum(g_s), sum(g_s * (zmask - e2)) of that source: partials[trunet_pw_bwd_nparts()][nchan][2].
  * Restrictions (else TRUNET_ENOTSUP, use trunet_conv_gemm + trunet_conv_wgrad): w.a_mode = TRUNET_PRO_BNBWD,
- * M in {32,64,96,128}, every segment pos_mul = pos_div = 1 and nchan % 32 == 0, sum nchan in {64,128,192}. */
+ * every segment pos_mul = pos_div = 1; M in {32,64,96,128} with nchan % 32 == 0 and sum nchan in {64,128,192} (MFMA kernel),
+ * or M <= 8 with nchan % 8 == 0 (vector-ALU kernel for the thin last decoder layer). */
 enum { TRUNET_DG_STORE = 1,  /* write the data gradient of this segment to `out`          */
        TRUNET_DG_MASK = 2,   /* ReLU backward: multiply by [e0*zmask + e1 > 0]             */
        TRUNET_DG_STATS = 4,  /* BatchNorm-backward statistics of the source (needs MASK)   */

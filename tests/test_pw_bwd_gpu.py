@@ -291,3 +291,26 @@ def test_thin_wgrad_first_conv():
 def test_thin_wgrad_last_pointwise():
     # decoder.5 Conv1d(128 -> 8, k = 1) over [x1 | skip], BatchNorm backward on dz
     _thin_wgrad_case(520, 6, 8, True, [(64, 6, 1, 0, 1, True, None), (64, 6, 1, 0, 1, False, None)])
+
+
+def test_thin_pointwise_backward_fused():
+    # decoder.5 Conv1d(128 -> 8, k = 1) + BatchNorm over [x1 (BN, crop by one on each side) | skip (ReLU-only source, raw)]
+    _run_case(520, 6, 8, [(64, 8, "bn"), (64, 6, "raw")], left=-1)
+    _run_case(300, 5, 8, [(64, 5, "bn_accum"), (64, 5, "raw")])
+
+
+def test_fused_backward_is_bitwise_repeatable(capsys):
+    """Every kernel in the body is meant to be deterministic (two-stage reductions, no float atomics).  An earlier
+    version of pw_bwd_kernel issued its epilogue loads as inline asm; under register pressure the compiler moved a
+    not-yet-arrived value and about one launch in a hundred wrote a wrong 32x32 tile.  Repeat identical launches with
+    cache / timing noise in between and compare every output bit for bit."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "dbg", "stress_pwbwd.py")
+    spec = importlib.util.spec_from_file_location("stress_pwbwd", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.run(300, 64, 128, [(128, "bn_accum")], 150, "enc", noise=True)
+    mod.run(300, 32, 64, [(64, "bn"), (128, "raw")], 100, "dec", noise=True)
+    out = capsys.readouterr().out
+    assert "enc: 0 bad of 150" in out and "dec: 0 bad of 100" in out, out

@@ -17,6 +17,8 @@ static inline int trunet_launch_status() {
 
 // wgrad_small.hip: vector-ALU weight gradient of the thin layers; TRUNET_ENOTSUP when the shape is not thin
 int trunet_launch_wgrad_small(const trunet_wgrad_args* h, hipStream_t st);
+// wgrad_small.hip: fused backward of a pointwise layer with <= 8 output rows (same contract as trunet_pw_bwd)
+int trunet_launch_pw_bwd_small(const trunet_pwbwd_args* H, hipStream_t st);
 
 // sum over the 32 lanes that share (lane >> 5)
 __device__ __forceinline__ float half_wave_sum(float v) {

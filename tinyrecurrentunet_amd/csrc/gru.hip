@@ -216,18 +216,18 @@ namespace {
 constexpr int TH = 128;    // hidden units
 constexpr int TS = 32;     // sequences per workgroup
 
-// global access as uniform row base (SGPR pair) + per-lane byte offset: sixteen rows x eight tensors of per-lane 64-bit
-// addresses would not fit the register budget next to W_hh.  The loaded value is usable after tg_fence16.
-__device__ __forceinline__ void tg_load(float& v, const float* sbase, int voff) {
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
+// Global rows as buffer resource (SGPR descriptor of a uniform base) + uniform SGPR row offset + one per-lane VGPR offset:
+// sixteen rows x eight tensors of per-lane 64-bit addresses would not fit the register budget next to W_hh, and these
+// intrinsics are tracked by the compiler (waits, hazards), unlike hand-written asm loads.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tg_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
 }
-__device__ __forceinline__ void tg_store(float* sbase, int voff, float v) {
-    asm volatile("global_store_dword %0, %1, %2" :: "v"(voff), "v"(v), "s"(sbase) : "memory");
+__device__ __forceinline__ float tg_load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
-#define TG_FENCE16(a, wait)                                                                                             \
-    asm volatile(wait : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),   \
-                 "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])     \
-                 :: "memory")
+__device__ __forceinline__ void tg_store(__amdgpu_buffer_rsrc_t r, int voff, int soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, voff, soff, 0);
+}
 
 __global__ __launch_bounds__(512, 2) void tgru_rec_fwd_kernel(const float* __restrict__ gi_all,
                                                               const float* __restrict__ whh,
@@ -265,25 +265,24 @@ __global__ __launch_bounds__(512, 2) void tgru_rec_fwd_kernel(const float* __res
     const size_t hrow = (size_t)(T + 1) * SP;        // row stride of hs
     const int voff_g = (int)((4 * hh * grow + c) * sizeof(float));     // per-lane part of a gi / gates address
     const int voff_h = (int)((4 * hh * hrow + c) * sizeof(float));     // per-lane part of an hs address
+    const int growb = (int)(grow * sizeof(float)), hrowb = (int)(hrow * sizeof(float));
+    const int planeb = (int)((size_t)TH * grow * sizeof(float));       // gate g of gi_all starts g planes further
+    const int gplaneb = planeb;                                        // gates planes [4][H][T][SP] have the same size
     for (int t = 0; t < T; ++t) {
         const int cur = t & 1;
-        float a0[16], a1[16], gin[16];
+        float gin[16];
         f32x16 acc[3];
         // kh = 0 waves seed the accumulators with gi (+ folded biases); gi_n stays aside, gh_n accumulates on b_hn alone
         if (kh == 0) {
-            const float* gb = gi_all + (size_t)(32 * ut) * grow + (size_t)t * SP + s0;      // uniform
+            const __amdgpu_buffer_rsrc_t rg = tg_rsrc(gi_all + (size_t)(32 * ut) * grow + (size_t)t * SP + s0);   // uniform
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const size_t ro = (size_t)((r & 3) + 8 * (r >> 2)) * grow;
-                tg_load(a0[r], gb + ro, voff_g);
-                tg_load(a1[r], gb + (size_t)TH * grow + ro, voff_g);
-                tg_load(gin[r], gb + (size_t)2 * TH * grow + ro, voff_g);
+                const int ro = ((r & 3) + 8 * (r >> 2)) * growb;
+                acc[0][r] = tg_load(rg, voff_g, ro);
+                acc[1][r] = tg_load(rg, voff_g, ro + planeb);
+                gin[r] = tg_load(rg, voff_g, ro + 2 * planeb);
+                acc[2][r] = bias_n[r];
             }
-            TG_FENCE16(a0, "s_waitcnt vmcnt(0)");
-            TG_FENCE16(a1, "");
-            TG_FENCE16(gin, "");
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[0][r] = a0[r]; acc[1][r] = a1[r]; acc[2][r] = bias_n[r]; }
         } else {
 #pragma unroll
             for (int g = 0; g < 3; ++g)
@@ -308,9 +307,8 @@ __global__ __launch_bounds__(512, 2) void tgru_rec_fwd_kernel(const float* __res
         __syncthreads();
         if (kh == 0) {
             float* hw = &hbuf[cur ^ 1][0][0];
-            float* hsb = hs + (size_t)(32 * ut) * hrow + (size_t)(t + 1) * SP + s0;        // uniform
-            float* gtb = gates ? gates + (size_t)(32 * ut) * grow + (size_t)t * SP + s0 : nullptr;
-            const size_t plane = (size_t)TH * grow;
+            const __amdgpu_buffer_rsrc_t rh = tg_rsrc(hs + (size_t)(32 * ut) * hrow + (size_t)(t + 1) * SP + s0);
+            const __amdgpu_buffer_rsrc_t rt = tg_rsrc(gates ? gates + (size_t)(32 * ut) * grow + (size_t)t * SP + s0 : hs);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ml = (r & 3) + 8 * (r >> 2);
@@ -324,13 +322,13 @@ __global__ __launch_bounds__(512, 2) void tgru_rec_fwd_kernel(const float* __res
                 const float hn = fmaf(zz, hprev[r] - nn, nn);
                 hprev[r] = hn;
                 hw[u * TS + c] = hn;
-                tg_store(hsb + (size_t)ml * hrow, voff_h, hn);
+                tg_store(rh, voff_h, ml * hrowb, hn);
                 if (gates) {
-                    float* gr = gtb + (size_t)ml * grow;
-                    tg_store(gr, voff_g, rr);
-                    tg_store(gr + plane, voff_g, zz);
-                    tg_store(gr + 2 * plane, voff_g, nn);
-                    tg_store(gr + 3 * plane, voff_g, gh);
+                    const int ro = ml * growb;
+                    tg_store(rt, voff_g, ro, rr);
+                    tg_store(rt, voff_g, ro + gplaneb, zz);
+                    tg_store(rt, voff_g, ro + 2 * gplaneb, nn);
+                    tg_store(rt, voff_g, ro + 3 * gplaneb, gh);
                 }
             }
         }
@@ -365,40 +363,35 @@ __global__ __launch_bounds__(512, 2) void tgru_rec_bwd_kernel(const float* __res
     for (int r = 0; r < 16; ++r) carry[r] = 0.f;
     const size_t grow = (size_t)T * SP;
     const size_t hrow = (size_t)(T + 1) * SP;
-    const size_t plane = (size_t)TH * grow;
     const int voff_g = (int)((4 * hh * grow + c) * sizeof(float));
     const int voff_h = (int)((4 * hh * hrow + c) * sizeof(float));
+    const int growb = (int)(grow * sizeof(float)), hrowb = (int)(hrow * sizeof(float));
+    const int planeb = (int)((size_t)TH * grow * sizeof(float));       // planes of gates / gate blocks of dgi, dgh
     const bool live = s0 + c < S;                    // padded sequences carry no gradient
 
     for (int t = T - 1; t >= 0; --t) {
         float dzd[16];                               // dh z: the direct path into h_{t-1}
         if (kh == 0) {
-            const float* dhb = dhs + (size_t)(32 * ut) * hrow + (size_t)(t + 1) * SP + s0;     // uniform bases
-            const float* hpb = hs + (size_t)(32 * ut) * hrow + (size_t)t * SP + s0;
-            const float* gtb = gates + (size_t)(32 * ut) * grow + (size_t)t * SP + s0;
-            float* gib = dgi_all + (size_t)(32 * ut) * grow + (size_t)t * SP + s0;
-            float* ghb = dgh_all + (size_t)(32 * ut) * grow + (size_t)t * SP + s0;
+            const __amdgpu_buffer_rsrc_t rdh = tg_rsrc(dhs + (size_t)(32 * ut) * hrow + (size_t)(t + 1) * SP + s0);   // uniform bases
+            const __amdgpu_buffer_rsrc_t rhp = tg_rsrc(hs + (size_t)(32 * ut) * hrow + (size_t)t * SP + s0);
+            const __amdgpu_buffer_rsrc_t rgt = tg_rsrc(gates + (size_t)(32 * ut) * grow + (size_t)t * SP + s0);
+            const __amdgpu_buffer_rsrc_t rgi = tg_rsrc(dgi_all + (size_t)(32 * ut) * grow + (size_t)t * SP + s0);
+            const __amdgpu_buffer_rsrc_t rgh = tg_rsrc(dgh_all + (size_t)(32 * ut) * grow + (size_t)t * SP + s0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {            // four rows at a time: 24 loads in flight
                 float v[4][6];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int r = 4 * q + i;
-                    const size_t mg = (size_t)((r & 3) + 8 * (r >> 2)) * grow;
-                    const size_t mh = (size_t)((r & 3) + 8 * (r >> 2)) * hrow;
-                    tg_load(v[i][0], dhb + mh, voff_h);
-                    tg_load(v[i][1], hpb + mh, voff_h);
-                    tg_load(v[i][2], gtb + mg, voff_g);
-                    tg_load(v[i][3], gtb + plane + mg, voff_g);
-                    tg_load(v[i][4], gtb + 2 * plane + mg, voff_g);
-                    tg_load(v[i][5], gtb + 3 * plane + mg, voff_g);
+                    const int mg = ((r & 3) + 8 * (r >> 2)) * growb;
+                    const int mh = ((r & 3) + 8 * (r >> 2)) * hrowb;
+                    v[i][0] = tg_load(rdh, voff_h, mh);
+                    v[i][1] = tg_load(rhp, voff_h, mh);
+                    v[i][2] = tg_load(rgt, voff_g, mg);
+                    v[i][3] = tg_load(rgt, voff_g, mg + planeb);
+                    v[i][4] = tg_load(rgt, voff_g, mg + 2 * planeb);
+                    v[i][5] = tg_load(rgt, voff_g, mg + 3 * planeb);
                 }
-                asm volatile("s_waitcnt vmcnt(0)"
-                             : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[0][2]), "+v"(v[0][3]), "+v"(v[0][4]), "+v"(v[0][5]),
-                               "+v"(v[1][0]), "+v"(v[1][1]), "+v"(v[1][2]), "+v"(v[1][3]), "+v"(v[1][4]), "+v"(v[1][5]),
-                               "+v"(v[2][0]), "+v"(v[2][1]), "+v"(v[2][2]), "+v"(v[2][3]), "+v"(v[2][4]), "+v"(v[2][5]),
-                               "+v"(v[3][0]), "+v"(v[3][1]), "+v"(v[3][2]), "+v"(v[3][3]), "+v"(v[3][4]), "+v"(v[3][5])
-                             :: "memory");
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int r = 4 * q + i;
@@ -415,13 +408,13 @@ __global__ __launch_bounds__(512, 2) void tgru_rec_bwd_kernel(const float* __res
                     dgb[u][c] = drp;
                     dgb[TH + u][c] = dzp;
                     dgb[2 * TH + u][c] = dnr;
-                    const size_t mg = (size_t)ml * grow;
-                    tg_store(gib + mg, voff_g, drp);
-                    tg_store(gib + (size_t)TH * grow + mg, voff_g, dzp);
-                    tg_store(gib + (size_t)2 * TH * grow + mg, voff_g, dnp);
-                    tg_store(ghb + mg, voff_g, drp);
-                    tg_store(ghb + (size_t)TH * grow + mg, voff_g, dzp);
-                    tg_store(ghb + (size_t)2 * TH * grow + mg, voff_g, dnr);
+                    const int mg = ml * growb;
+                    tg_store(rgi, voff_g, mg, drp);
+                    tg_store(rgi, voff_g, mg + planeb, dzp);
+                    tg_store(rgi, voff_g, mg + 2 * planeb, dnp);
+                    tg_store(rgh, voff_g, mg, drp);
+                    tg_store(rgh, voff_g, mg + planeb, dzp);
+                    tg_store(rgh, voff_g, mg + 2 * planeb, dnr);
                 }
             }
         }
@@ -454,7 +447,7 @@ __global__ __launch_bounds__(512, 2) void tgru_rec_bwd_kernel(const float* __res
 extern "C" int trunet_tgru_rec_bwd(const float* dhs, const float* hs, const float* gates, const float* w_hh, float* dgi_all,
                                    float* dgh_all, int H, int T, int SP, int S, void* stream) {
     if (!dhs || !hs || !gates || !w_hh || !dgi_all || !dgh_all || T <= 0 || SP <= 0 || (SP % TS) || S > SP) return TRUNET_EINVAL;
-    if (H != TH) return TRUNET_ENOTSUP;
+    if (H != TH || (size_t)4 * TH * T * SP * sizeof(float) >= ((size_t)1 << 31)) return TRUNET_ENOTSUP;   // 32-bit row offsets
     hipLaunchKernelGGL(tgru_rec_bwd_kernel, dim3(SP / TS), dim3(512), 0, (hipStream_t)stream, dhs, hs, gates, w_hh, dgi_all,
                        dgh_all, T, SP, S);
     return trunet_launch_status();
@@ -463,7 +456,7 @@ extern "C" int trunet_tgru_rec_bwd(const float* dhs, const float* hs, const floa
 extern "C" int trunet_tgru_rec_fwd(const float* gi_all, const float* w_hh, const float* b_hn, float* hs, float* gates,
                                    int H, int T, int SP, void* stream) {
     if (!gi_all || !w_hh || !b_hn || !hs || T <= 0 || SP <= 0 || (SP % TS)) return TRUNET_EINVAL;
-    if (H != TH) return TRUNET_ENOTSUP;
+    if (H != TH || (size_t)4 * TH * T * SP * sizeof(float) >= ((size_t)1 << 31)) return TRUNET_ENOTSUP;   // 32-bit row offsets
     hipLaunchKernelGGL(tgru_rec_fwd_kernel, dim3(SP / TS), dim3(512), 0, (hipStream_t)stream, gi_all, w_hh, b_hn, hs, gates,
                        T, SP);
     return trunet_launch_status();

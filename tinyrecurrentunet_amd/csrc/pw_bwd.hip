@@ -68,6 +68,21 @@ __device__ __forceinline__ PSegPos pwb_seg_pos(const trunet_seg& sg, int p) {
     return r;
 }
 
+// Global rows as buffer resource (SGPR descriptor of a uniform base) + uniform SGPR row offset + one per-lane VGPR
+// offset: 64-bit per-row addresses for 16 rows x 3 tensors would not fit the register budget next to the W^T fragments,
+// and -- unlike hand-written asm loads -- the compiler tracks these, so a value is never copied or spilled before it has
+// arrived (an earlier inline-asm version produced a wrong 32x32 tile about once in a hundred launches under register
+// pressure).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pwb_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float pwb_bload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void pwb_bstore(__amdgpu_buffer_rsrc_t r, int voff, int soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, voff, soff, 0);
+}
+
 // wave-uniform values the compiler cannot prove uniform (they pass through per-wave role tables)
 __device__ __forceinline__ int pwb_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ size_t pwb_uniform(size_t v) {
@@ -441,28 +456,23 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
         // State of the row tile whose epilogue is pending: accumulator and epilogue operands (registers only).
         f32x16 dacc;
         float zv[16], ov[16];
-        // head: hand-issued epilogue operand loads (uniform row base + per-lane offset keeps 64-bit addresses out of
-        // the VGPR budget), then the MFMAs over the dz rows
+        // head: epilogue operand loads (buffer resource + uniform row offset + per-lane offset), then the MFMAs over the
+        // dz rows
         auto dgrad_head = [&](const DUnit& u, const DRun& dr, const float (&af)[AK], const float* S, int n0)
                               __attribute__((always_inline)) {
-            const float* zb = pwb_uniform(dr.zb);
-            const float* ob = pwb_uniform(dr.ob);
-            const size_t dstride = pwb_uniform(dr.dstride);
+            const __amdgpu_buffer_rsrc_t rz = pwb_rsrc(pwb_uniform(dr.zb));
+            const __amdgpu_buffer_rsrc_t ro = pwb_rsrc(pwb_uniform(dr.ob));
+            const int rowb = (int)(pwb_uniform(dr.dstride) * sizeof(float));      // bytes between channels
+            const int nb = n0 * (int)sizeof(float);
 #pragma unroll
             for (int r = 0; r < 16; ++r) { zv[r] = 0.f; ov[r] = 0.f; }
             if ((u.flags & TRUNET_DG_MASK) && !(PWB_ABL & 1)) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float* rp = zb + (size_t)((r & 3) + 8 * (r >> 2)) * dstride + n0;
-                    asm volatile("global_load_dword %0, %1, %2" : "=v"(zv[r]) : "v"(dr.voff), "s"(rp) : "memory");
-                }
+                for (int r = 0; r < 16; ++r) zv[r] = pwb_bload(rz, dr.voff, ((r & 3) + 8 * (r >> 2)) * rowb + nb);
             }
             if ((u.flags & TRUNET_DG_ACCUM) && !(PWB_ABL & 1)) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float* rp = ob + (size_t)((r & 3) + 8 * (r >> 2)) * dstride + n0;
-                    asm volatile("global_load_dword %0, %1, %2" : "=v"(ov[r]) : "v"(dr.voff), "s"(rp) : "memory");
-                }
+                for (int r = 0; r < 16; ++r) ov[r] = pwb_bload(ro, dr.voff, ((r & 3) + 8 * (r >> 2)) * rowb + nb);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) dacc[r] = 0.f;
@@ -478,22 +488,9 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
         auto dgrad_tail = [&](auto FLc, const DUnit& u, const DRun& dr, float (&st1)[16], float (&st2)[16], int n0)
                               __attribute__((always_inline)) {
             constexpr int FL = decltype(FLc)::value;
-            float* ob = pwb_uniform(dr.ob);
-            const size_t dstride = pwb_uniform(dr.dstride);
-            // The stores below are inline asm: the compiler's hazard recogniser does not pad between the last MFMA
-            // (16 passes) and an asm instruction that reads its result, so wait it out here (>= 19 wait states).
-            asm volatile("s_nop 15\n\ts_nop 7" : "+v"(dacc) :: "memory");
-            // the loaded values become visible to the compiler only through these two statements
-            if (FL & (TRUNET_DG_MASK | TRUNET_DG_ACCUM)) {
-                asm volatile("s_waitcnt vmcnt(0)"
-                             : "+v"(zv[0]), "+v"(zv[1]), "+v"(zv[2]), "+v"(zv[3]), "+v"(zv[4]), "+v"(zv[5]), "+v"(zv[6]),
-                               "+v"(zv[7]), "+v"(zv[8]), "+v"(zv[9]), "+v"(zv[10]), "+v"(zv[11]), "+v"(zv[12]),
-                               "+v"(zv[13]), "+v"(zv[14]), "+v"(zv[15]) :: "memory");
-                asm volatile(""
-                             : "+v"(ov[0]), "+v"(ov[1]), "+v"(ov[2]), "+v"(ov[3]), "+v"(ov[4]), "+v"(ov[5]), "+v"(ov[6]),
-                               "+v"(ov[7]), "+v"(ov[8]), "+v"(ov[9]), "+v"(ov[10]), "+v"(ov[11]), "+v"(ov[12]),
-                               "+v"(ov[13]), "+v"(ov[14]), "+v"(ov[15]) :: "memory");
-            }
+            const __amdgpu_buffer_rsrc_t ro = pwb_rsrc(pwb_uniform(dr.ob));
+            const int rowb = (int)(pwb_uniform(dr.dstride) * sizeof(float));
+            const int nb = n0 * (int)sizeof(float);
             const f32x4* CBs = CB + u.cb + 32 * u.ct + 4 * h;
             const bool fin = n0 + c < a.N;
 #pragma unroll
@@ -507,8 +504,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
                     k = CBs[ml];
                     val = (fmaf(k[0], zv[r], k[1]) > 0.f) ? val : 0.f;
                 }
-                float* rp = ob + (size_t)ml * dstride + n0;
-                if (!(PWB_ABL & 2)) asm volatile("global_store_dword %0, %1, %2" :: "v"(dr.voff), "v"(val), "s"(rp) : "memory");
+                if (!(PWB_ABL & 2)) pwb_bstore(ro, dr.voff, ml * rowb + nb, val);
                 if (FL & TRUNET_DG_STATS) {
                     const float x = fin ? val : 0.f;
                     st1[r] += x;
@@ -609,10 +605,26 @@ extern "C" int trunet_pw_bwd(const trunet_pwbwd_args* H, void* stream) {
     if (!h->a0 || !h->a1 || !h->w_partials || h->nseg < 1 || h->nseg > TRUNET_MAX_SEG) return TRUNET_EINVAL;
     if (h->NP <= 0 || (h->NP % TRUNET_TILE_FRAMES) != 0 || h->N > h->NP || h->P <= 0 || h->M <= 0) return TRUNET_EINVAL;
     if (h->a_mode != TRUNET_PRO_BNBWD || !h->ac0 || !h->ac1 || !h->ac2) return TRUNET_ENOTSUP;
+    hipStream_t st = (hipStream_t)stream;
+    if (h->M <= 8) {
+        // thin layer (decoder.5's Conv1d(128 -> 8)): vector-ALU kernel, same contract
+        for (int s = 0; s < h->nseg; ++s) {
+            const trunet_seg& sg = h->seg[s];
+            const trunet_dgrad_out& dg = H->dg[s];
+            if (!sg.src0 || sg.nchan <= 0 || sg.pos_mul != 1 || sg.pos_div != 1 || sg.mode == TRUNET_PRO_BNBWD) return TRUNET_ENOTSUP;
+            if (sg.mode == TRUNET_PRO_BNRELU && (!sg.c0 || !sg.c1)) return TRUNET_EINVAL;
+            if (!(dg.flags & TRUNET_DG_STORE) || !dg.out) return TRUNET_ENOTSUP;
+            if ((dg.flags & TRUNET_DG_STATS) && (!(dg.flags & TRUNET_DG_MASK) || !dg.partials || !dg.e2)) return TRUNET_EINVAL;
+            if (dg.flags & TRUNET_DG_STATS) {
+                const size_t bytes = (size_t)trunet_pw_bwd_nparts() * sg.nchan * 2 * sizeof(float);
+                if (hipMemsetAsync(dg.partials, 0, bytes, st) != hipSuccess) return TRUNET_ELAUNCH;
+            }
+        }
+        return trunet_launch_pw_bwd_small(H, st);
+    }
     if (h->M > 128 || (h->M % 32) != 0) return TRUNET_ENOTSUP;
     const int MA = h->M <= 64 ? 64 : 128;
     int ktiles = 0, ntot = 0;
-    hipStream_t st = (hipStream_t)stream;
     for (int s = 0; s < h->nseg; ++s) {
         const trunet_seg& sg = h->seg[s];
         const trunet_dgrad_out& dg = H->dg[s];
@@ -624,6 +636,8 @@ extern "C" int trunet_pw_bwd(const trunet_pwbwd_args* H, void* stream) {
         if ((dg.flags & TRUNET_DG_MASK) && !dg.zmask) return TRUNET_EINVAL;
         if ((dg.flags & TRUNET_DG_STATS) && (!(dg.flags & TRUNET_DG_MASK) || !dg.partials)) return TRUNET_EINVAL;
         if ((dg.flags & TRUNET_DG_ACCUM) && !(dg.flags & TRUNET_DG_MASK)) return TRUNET_ENOTSUP;
+        // the epilogue addresses rows as 32-bit byte offsets from a per-(row tile, position) base
+        if ((size_t)sg.L * h->NP * sizeof(float) * 36 >= ((size_t)1 << 31)) return TRUNET_ENOTSUP;
         ktiles += sg.nchan / 32;
         ntot += sg.nchan;
     }

@@ -181,3 +181,157 @@ int trunet_launch_wgrad_small(const trunet_wgrad_args* h, hipStream_t st) {
     }
     return TRUNET_ENOTSUP;
 }
+
+// =====================================================================================
+// Fused backward of a THIN pointwise layer (<= 8 output rows: decoder.5's Conv1d(128 -> 8) + BatchNorm): the same
+// contract as pw_bwd_kernel (trunet_pw_bwd), on the vector ALU.  A role = 8 channels of one source segment; a block
+// holds 16 roles x 16 lanes and walks (position, 64-frame chunk) items, 4 frames per lane: the 16 roles read the same
+// dy / z rows (one fetch, served 16 times from L1), every role forms dz = ca dy + cb z + cc, accumulates its dW[8][8]
+// in registers and writes its 8 rows of the data gradient g = W^T dz (+ previous content) (* ReLU mask) with their
+// BatchNorm-backward sums.  One pass over (dy, z, sources) instead of three launches that each re-read dy, z.
+// grid = (ceil(roles / 16), 256 partial images).
+// =====================================================================================
+namespace {
+
+__global__ __launch_bounds__(256) void pw_bwd_small_kernel(const trunet_pwbwd_args A, const int ngc_max, const int nroles) {
+    const trunet_wgrad_args& a = A.w;
+    __shared__ float Ws[16][64];             // per role: W[m][c0 + j]
+    const int tid = threadIdx.x;
+    const int l16 = tid & 15;
+    const int rl = tid >> 4;                 // role slot inside the block
+    const int role = blockIdx.x * 16 + rl;
+    const bool has_role = role < nroles;
+    const int cg = has_role ? role % ngc_max : 0, s = has_role ? role / ngc_max : 0;
+    const trunet_seg& sg = a.seg[s];
+    const trunet_dgrad_out& dg = A.dg[s];
+    const int c0 = cg * 8;
+    const bool act_role = has_role && c0 < sg.nchan;
+    const bool bias_role = (role == 0);
+    const int fl = dg.flags;
+    for (int idx = l16; idx < 64; idx += 16) {
+        const int m = idx >> 3, j = idx & 7;
+        Ws[rl][idx] = (act_role && m < a.M) ? A.W[(size_t)(m + a.w_m_off) * a.ldw_m + (size_t)(c0 + j) * a.ldw_c + sg.woff] : 0.f;
+    }
+    __syncthreads();
+    float accW[8][8], bsum[8], s1[8], s2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        bsum[i] = 0.f; s1[i] = 0.f; s2[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) accW[i][j] = 0.f;
+    }
+    const bool on = sg.mode == TRUNET_PRO_BNRELU;
+    const int nch = a.NP / 64;
+    const int items = a.P * nch;
+    const size_t dstr = (size_t)a.a_L * a.NP;
+    const size_t sstr = (size_t)sg.L * a.NP;
+    for (int it = blockIdx.y; it < items; it += gridDim.y) {
+        const int pi = it / nch;
+        const int p = a.p_begin + pi;
+        const int n = (it - pi * nch) * 64 + 4 * l16;
+        const int q = p + sg.pos_off;
+        const bool valid = act_role && q >= 0 && q < sg.L;
+        if (!valid && !bias_role) continue;
+        f32x4 dz[8];
+        {
+            const float* pdy = a.a0 + ((size_t)a.a_m_off * a.a_L + p + a.a_pos_off) * a.NP + n;
+            const float* pz = a.a1 + (pdy - a.a0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int mm = min(i, a.M - 1);
+                const f32x4 dv = *(const f32x4*)(pdy + (size_t)mm * dstr);
+                const f32x4 zv = *(const f32x4*)(pz + (size_t)mm * dstr);
+                const float ka = (i < a.M) ? a.ac0[mm + a.a_m_off] : 0.f;
+                const float kb = (i < a.M) ? a.ac1[mm + a.a_m_off] : 0.f;
+                const float kc = (i < a.M) ? a.ac2[mm + a.a_m_off] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dz[i][e] = (n + e < a.N) ? fmaf(ka, dv[e], fmaf(kb, zv[e], kc)) : 0.f;
+            }
+        }
+        if (bias_role) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bsum[i] += (dz[i][0] + dz[i][1]) + (dz[i][2] + dz[i][3]);
+        }
+        if (!valid) continue;
+        const float* psrc = sg.src0 + ((size_t)c0 * sg.L + q) * a.NP + n;
+        float* pout = dg.out + ((size_t)c0 * sg.L + q) * a.NP + n;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const f32x4 zs = *(const f32x4*)(psrc + (size_t)j * sstr);
+            const float sc = on ? sg.c0[c0 + j] : 1.f, sh = on ? sg.c1[c0 + j] : 0.f;
+            f32x4 g = {0.f, 0.f, 0.f, 0.f};
+            if (fl & TRUNET_DG_ACCUM) g = *(const f32x4*)(pout + (size_t)j * sstr);
+            f32x4 act;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pre = fmaf(zs[e], sc, sh);
+                act[e] = on ? fmaxf(pre, 0.f) : pre;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float w = Ws[rl][i * 8 + j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    accW[i][j] = fmaf(dz[i][e], act[e], accW[i][j]);
+                    g[e] = fmaf(w, dz[i][e], g[e]);
+                }
+            }
+            if (fl & TRUNET_DG_MASK) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = (fmaf(zs[e], sc, sh) > 0.f) ? g[e] : 0.f;
+            }
+            *(f32x4*)(pout + (size_t)j * sstr) = g;
+            if (fl & TRUNET_DG_STATS) {
+                const float mu = dg.e2[c0 + j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = (n + e < a.N) ? g[e] : 0.f;
+                    s1[j] += x;
+                    s2[j] = fmaf(x, zs[e] - mu, s2[j]);
+                }
+            }
+        }
+    }
+    // ---- reduce over the 16 lanes of the role, then this role's entries of the partial image
+    auto sum16 = [](float v) {
+        v += __shfl_xor(v, 8, 16); v += __shfl_xor(v, 4, 16); v += __shfl_xor(v, 2, 16); v += __shfl_xor(v, 1, 16);
+        return v;
+    };
+    float* img = a.w_partials + (size_t)blockIdx.y * a.w_numel;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = sum16(accW[i][j]);
+            if (l16 == 0 && act_role && i < a.M && c0 + j < sg.nchan)
+                img[(size_t)(i + a.w_m_off) * a.ldw_m + (size_t)(c0 + j) * a.ldw_c + sg.woff] = v;
+        }
+        const float b = sum16(bsum[i]);
+        if (l16 == 0 && bias_role && a.b_partials && i < a.M)
+            a.b_partials[(size_t)blockIdx.y * a.b_stride + a.b_off + i] = b;
+        const float t1 = sum16(s1[i]);
+        const float t2 = sum16(s2[i]);
+        if (l16 == 0 && act_role && (fl & TRUNET_DG_STATS) && c0 + i < sg.nchan) {
+            float* pp = dg.partials + ((size_t)blockIdx.y * sg.nchan + c0 + i) * 2;
+            pp[0] = t1;
+            pp[1] = t2;
+        }
+    }
+}
+
+}  // namespace
+
+// called by trunet_pw_bwd (pw_bwd.hip) when the layer has <= 8 output rows; arguments already validated there
+int trunet_launch_pw_bwd_small(const trunet_pwbwd_args* H, hipStream_t st) {
+    const trunet_wgrad_args* h = &H->w;
+    int maxc = 0;
+    for (int s = 0; s < h->nseg; ++s) {
+        if (h->seg[s].nchan % 8) return TRUNET_ENOTSUP;
+        maxc = h->seg[s].nchan > maxc ? h->seg[s].nchan : maxc;
+    }
+    if (h->NP % 64) return TRUNET_EINVAL;
+    const int ngc = maxc / 8;
+    const int nroles = h->nseg * ngc;
+    hipLaunchKernelGGL(pw_bwd_small_kernel, dim3((nroles + 15) / 16, WS_GRID), dim3(256), 0, st, *H, ngc, nroles);
+    return trunet_launch_status();
+}

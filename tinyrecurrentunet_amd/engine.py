@@ -28,6 +28,8 @@ BN_MOM = 0.1
 # trunet_conv_wgrad + trunet_conv_gemm; TRUNET_FUSED_PWBWD=0 keeps the separate launches (A/B measurements).
 FUSED_PWBWD = os.environ.get("TRUNET_FUSED_PWBWD", "1") != "0"
 
+FUSED_THIN = os.environ.get("TRUNET_FUSED_THIN", "0") == "1"
+
 # TGRU time loop as a host loop of (GEMM, cell) launch pairs instead of the persistent kernels (A/B, other H)
 TGRU_LOOP = os.environ.get("TRUNET_TGRU_LOOP", "0") == "1"
 
@@ -686,7 +688,8 @@ class TRUNetEngine:
             d.flags = fl
         if PROFILE is not None:
             fl_ = 4.0 * N * M * sum(s.nchan * _seg_positions(s, 0, P) for s in segs)
-            name = "pw_bwd_kernel<%d, %s>" % (32 if M <= 64 else 64, "true" if K == 192 else "false")
+            name = "pw_bwd_small_kernel" if M <= 8 else \
+                "pw_bwd_kernel<%d, %s>" % (32 if M <= 64 else 64, "true" if K == 192 else "false")
             with _Timed(name, fl_, "M%d K%s P%d" % (M, "+".join(str(s.nchan) for s in segs), P)):
                 check(lib.trunet_pw_bwd(a, L.stream()), "pw_bwd")
         else:
@@ -757,7 +760,10 @@ class TRUNetEngine:
                 if q1 < x1.L:
                     dy_x1[:, q1:].zero_()
             g_skip = w.get("dy:enc%d" % (5 - i), (skip.C, skip.L, NP)) if skip is not None else None
-            if FUSED_PWBWD and pw.out_channels % 32 == 0:
+            # decoder.5's 8-row layer stays on the three separate launches (1.64 ms): trunet_pw_bwd's vector-ALU variant
+            # for <= 8 rows is correct but measured slower at this size (2.7-3.3 ms: 256 partial images = 256 blocks
+            # leave too few waves in flight); TRUNET_FUSED_THIN=1 selects it
+            if FUSED_PWBWD and (pw.out_channels % 32 == 0 or (pw.out_channels <= 8 and FUSED_THIN)):
                 outs = [dict(out=dy_x1, src=x1)] + ([dict(out=g_skip)] if skip is not None else [])
                 self._pw_bwd(w, N=N, NP=NP, P=Lp, M=pw.out_channels, dz=dy, dz1=z, dz_bn=bn, W=pw.weight,
                              bias=pw.bias, segs=srcs, outs=outs, grads=grads)
@@ -811,12 +817,9 @@ class TRUNetEngine:
                         ldw_m=Hh, ldw_c=1, segs=[hseg], grads=grads, bias=bhh, b_off=0)
             self._wgrad(w, N=N, NP=NP, P=Lg, M=Hh, dz=dghn, dz_L=Lg, dz_bn=None, a_m_off=d * Hh, w_m_off=2 * Hh,
                         W=whh, ldw_m=Hh, ldw_c=1, segs=[hseg], grads=grads, bias=bhh, b_off=2 * Hh)
-            # input projection weights: rows of dgi for this direction (3H = 128 + 64)
-            self._wgrad(w, N=N, NP=NP, P=Lg, M=2 * Hh, dz=dgi, dz_L=Lg, dz_bn=None, a_m_off=d * 3 * Hh, W=wih_p,
+            # input projection weights: all 3H = 192 rows of dgi for this direction in one launch
+            self._wgrad(w, N=N, NP=NP, P=Lg, M=3 * Hh, dz=dgi, dz_L=Lg, dz_bn=None, a_m_off=d * 3 * Hh, W=wih_p,
                         ldw_m=gru.input_size, ldw_c=1, segs=[enc5.seg()], grads=grads, bias=bih_p, b_off=0)
-            self._wgrad(w, N=N, NP=NP, P=Lg, M=Hh, dz=dgi, dz_L=Lg, dz_bn=None, a_m_off=d * 3 * Hh + 2 * Hh,
-                        w_m_off=2 * Hh, W=wih_p, ldw_m=gru.input_size, ldw_c=1, segs=[enc5.seg()], grads=grads,
-                        bias=bih_p, b_off=2 * Hh)
         # data gradient of the projection -> dy of enc5's BN
         wih = w.t["wih"]
         dy5 = w.get("dy:enc5", (enc5.C, enc5.L, NP))
