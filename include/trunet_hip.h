@@ -278,6 +278,10 @@ int trunet_stft_loss_fwd(const float* x, const float* y, const float* win, const
                          int B, int L, int n, int hop, void* stream);
 int trunet_stft_loss_bwd(const float* x, const float* y, const float* win, const float* tw, const float* coef,
                          float* gx, int B, int L, int n, int hop, void* stream);
+/* trunet_stft_loss_bwd without float atomics: the windowed frame gradients go to `frames` (B, frames, win_length: the
+ * window's support, centred in n) and a gather sums them per sample; gx is written (not accumulated), deterministic. */
+int trunet_stft_loss_bwd_gather(const float* x, const float* y, const float* win, const float* tw, const float* coef,
+                                float* frames, float* gx, int B, int L, int n, int hop, int win_length, void* stream);
 /* stft() of stft_loss.py:9-30: magnitudes sqrt(clamp(re^2+im^2, 1e-7)) of the Hann-windowed, centre/reflect-padded STFT
  * as (B, 1 + L/hop, n/2 + 1); y / ymag may be NULL (one signal), else both signals share one complex FFT. */
 int trunet_stft_mag(const float* x, const float* y, const float* win, const float* tw, float* xmag, float* ymag, int B,

@@ -118,6 +118,7 @@ def _declare(L):
         "trunet_stft_loss_fwd": [p, p, p, p, p, i, i, i, i, p],
         "trunet_stft_loss_bwd": [p, p, p, p, p, p, i, i, i, i, p],
         "trunet_stft_mag": [p, p, p, p, p, p, i, i, i, i, p],
+        "trunet_stft_loss_bwd_gather": [p, p, p, p, p, p, p, i, i, i, i, i, p],
         "trunet_phm_fwd": [p, p, p, i64, f, p],
         "trunet_debug_mfma_peak": [p, i, i, p],
     }

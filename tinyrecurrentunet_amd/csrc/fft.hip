@@ -347,7 +347,8 @@ __global__ __launch_bounds__(256) void reduce_cols_kernel(const float* __restric
 __global__ __launch_bounds__(256) void stft_loss_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                             const float* __restrict__ win, const cpx* __restrict__ tw,
                                                             const float* __restrict__ coef, float* __restrict__ gx, int L,
-                                                            int n, int logn, int hop) {
+                                                            int n, int logn, int hop, float* __restrict__ fr, int wl,
+                                                            int left) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
     cpx* sa = (cpx*)smraw;
     cpx* sb = sa + n;
@@ -381,6 +382,12 @@ __global__ __launch_bounds__(256) void stft_loss_bwd_kernel(const float* __restr
         other[k] = G;
     }
     const cpx* g = fft_lds(other, Z, n, logn, tw, true);
+    if (fr) {
+        // windowed time-domain gradient of this frame, the window's support only: summed per sample by ola_gather_kernel
+        float* fo = fr + ((size_t)b * gridDim.x + f) * wl;
+        for (int i = threadIdx.x; i < wl; i += 256) fo[i] = win[left + i] * g[left + i].x;
+        return;
+    }
     float* gb = gx + (size_t)b * L;
     for (int i = threadIdx.x; i < n; i += 256) {
         const float w = win[i];
@@ -389,6 +396,34 @@ __global__ __launch_bounds__(256) void stft_loss_bwd_kernel(const float* __restr
             atomicAdd(gb + j, w * g[i].x);
         }
     }
+}
+
+// gx[b][j] = sum over the frames (and, near the ends, the reflected positions) whose window support covers sample j:
+// the overlap-add of stft_loss_bwd_kernel's frames as a gather -- no float atomics, deterministic.
+__global__ __launch_bounds__(256) void ola_gather_kernel(const float* __restrict__ fr, float* __restrict__ gx, int L, int n,
+                                                         int hop, int nframes, int wl, int left) {
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= L) return;
+    const float* fb = fr + (size_t)b * nframes * wl;
+    float acc = 0.f;
+    // positions v of the reflect-padded signal that map onto sample j: v = j, v = -j (j > 0), v = 2(L-1) - j (j < L-1)
+#pragma unroll
+    for (int which = 0; which < 3; ++which) {
+        int v;
+        if (which == 0) v = j;
+        else if (which == 1) { if (j == 0) continue; v = -j; }
+        else { if (j == L - 1) continue; v = 2 * (L - 1) - j; }
+        // frame f covers v when left <= v - f*hop + n/2 < left + wl
+        const int hi = v + n / 2 - left;                 // f*hop <= hi
+        const int lo = v + n / 2 - left - wl + 1;        // f*hop >= lo
+        if (hi < 0) continue;
+        int f0 = lo <= 0 ? 0 : (lo + hop - 1) / hop;
+        int f1 = hi / hop;
+        if (f1 > nframes - 1) f1 = nframes - 1;
+        for (int f = f0; f <= f1; ++f) acc += fb[(size_t)f * wl + (v - f * hop + n / 2 - left)];
+    }
+    gx[(size_t)b * L + j] = acc;
 }
 
 __global__ void phm_kernel(const float2* __restrict__ m, const float2* __restrict__ e, float* __restrict__ out,
@@ -475,7 +510,23 @@ extern "C" int trunet_stft_loss_bwd(const float* x, const float* y, const float*
     if (!x || !y || !win || !tw || !coef || !gx || B <= 0 || logn < 3 || n > 4096 || hop <= 0 || L <= n / 2) return TRUNET_EINVAL;
     const int nframes = 1 + L / hop;
     hipLaunchKernelGGL(stft_loss_bwd_kernel, dim3(nframes, B), dim3(256), 2 * n * sizeof(cpx), ST, x, y, win, (const cpx*)tw,
-                       coef, gx, L, n, logn, hop);
+                       coef, gx, L, n, logn, hop, (float*)nullptr, 0, 0);
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_stft_loss_bwd_gather(const float* x, const float* y, const float* win, const float* tw,
+                                           const float* coef, float* frames, float* gx, int B, int L, int n, int hop,
+                                           int win_length, void* stream) {
+    const int logn = ilog2(n);
+    if (!x || !y || !win || !tw || !coef || !frames || !gx || B <= 0 || logn < 3 || n > 4096 || hop <= 0 || L <= n / 2 ||
+        win_length <= 0 || win_length > n)
+        return TRUNET_EINVAL;
+    const int nframes = 1 + L / hop;
+    const int left = (n - win_length) / 2;
+    hipLaunchKernelGGL(stft_loss_bwd_kernel, dim3(nframes, B), dim3(256), 2 * n * sizeof(cpx), ST, x, y, win, (const cpx*)tw,
+                       coef, gx, L, n, logn, hop, frames, win_length, left);
+    hipLaunchKernelGGL(ola_gather_kernel, dim3((L + 255) / 256, B), dim3(256), 0, ST, frames, gx, L, n, hop, nframes,
+                       win_length, left);
     return trunet_launch_status();
 }
 

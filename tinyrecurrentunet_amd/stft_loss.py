@@ -39,7 +39,7 @@ class _STFTLossFn(torch.autograd.Function):
     """(x, y) -> (sc, mag) of one resolution; gradient w.r.t. x only (y is the ground truth)."""
 
     @staticmethod
-    def forward(ctx, x, y, win, n, hop):
+    def forward(ctx, x, y, win, n, hop, wl=None):
         x = x.contiguous().float()
         y = y.contiguous().float()
         B, Ln = x.shape
@@ -55,7 +55,7 @@ class _STFTLossFn(torch.autograd.Function):
         sc = torch.sqrt(sums[0]) / torch.sqrt(sums[1])
         mag = sums[2] / count
         ctx.save_for_backward(x, y, win, tw, sums)
-        ctx.n, ctx.hop, ctx.count = n, hop, count
+        ctx.n, ctx.hop, ctx.count, ctx.wl = n, hop, count, wl
         return sc, mag
 
     @staticmethod
@@ -63,10 +63,17 @@ class _STFTLossFn(torch.autograd.Function):
         x, y, win, tw, sums = ctx.saved_tensors
         B, Ln = x.shape
         coef = torch.stack([g_sc / (torch.sqrt(sums[0]) * torch.sqrt(sums[1])), g_mag / ctx.count]).float().contiguous()
-        gx = torch.zeros_like(x)
-        check(L.lib().trunet_stft_loss_bwd(ptr(x), ptr(y), ptr(win), ptr(tw), ptr(coef), ptr(gx), B, Ln, ctx.n,
-                                           ctx.hop, L.stream()), "stft_loss_bwd")
-        return gx, None, None, None, None
+        if ctx.wl is not None:      # overlap-add as a gather over the window's support: no float atomics
+            nfr = 1 + Ln // ctx.hop
+            frames = torch.empty((B, nfr, ctx.wl), device=x.device, dtype=torch.float32)
+            gx = torch.empty_like(x)
+            check(L.lib().trunet_stft_loss_bwd_gather(ptr(x), ptr(y), ptr(win), ptr(tw), ptr(coef), ptr(frames), ptr(gx),
+                                                      B, Ln, ctx.n, ctx.hop, ctx.wl, L.stream()), "stft_loss_bwd_gather")
+        else:
+            gx = torch.zeros_like(x)
+            check(L.lib().trunet_stft_loss_bwd(ptr(x), ptr(y), ptr(win), ptr(tw), ptr(coef), ptr(gx), B, Ln, ctx.n,
+                                               ctx.hop, L.stream()), "stft_loss_bwd")
+        return gx, None, None, None, None, None
 
 
 class SpectralConvergenceLoss(nn.Module):
@@ -101,7 +108,7 @@ class STFTLoss(nn.Module):
             raise L.TrunetHipError("tinyrecurrentunet_amd.stft_loss runs on MI355X only")
         if self._wpad is None or self._wpad.device != x.device:
             self._wpad = _padded_window(self.window.to(x.device), self.fft_size)
-        return _STFTLossFn.apply(x, y, self._wpad, self.fft_size, self.shift_size)
+        return _STFTLossFn.apply(x, y, self._wpad, self.fft_size, self.shift_size, self.win_length)
 
 
 class MultiResolutionSTFTLoss(nn.Module):
