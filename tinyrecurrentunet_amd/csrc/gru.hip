@@ -15,7 +15,16 @@ namespace {
 constexpr int H = 64;
 constexpr int GF = 64;  // frames per workgroup
 
+// Gate nonlinearities on the hardware exp2 / rcp (v_exp_f32, v_rcp_f32: ~1 ulp each) instead of libm's expf / tanhf /
+// IEEE division: sigmoid to ~3e-7 relative, tanh to ~2e-7 ABSOLUTE (1 - 2/(1+e^{2x}) cancels for small x, which is
+// harmless where n enters h' = (1-z) n + z h additively).  The gate math was the largest part of a recurrence step.
+#ifndef GRU_LIBM
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
+#else
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return tanhf(x); }
+#endif
 
 __global__ __launch_bounds__(256, 1) void gru_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ whh0,
                                                          const float* __restrict__ bhh0, const float* __restrict__ whh1,
@@ -81,7 +90,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_kernel(const float* __restrict
                 rr[e] = sigmoidf_(acc[0][e][r]);
                 zz[e] = sigmoidf_(acc[1][e][r]);
                 gh[e] = acc[2][e][r];
-                nn[e] = tanhf(fmaf(rr[e], gh[e], gin[r][e]));
+                nn[e] = tanhf_(fmaf(rr[e], gh[e], gin[r][e]));
                 hn[e] = fmaf(zz[e], hprev[r][e] - nn[e], nn[e]);
                 hprev[r][e] = hn[e];
             }
@@ -318,7 +327,7 @@ __global__ __launch_bounds__(512, 2) void tgru_rec_fwd_kernel(const float* __res
                 const float gh = acc[2][r] + part[ut][2][r][lane];
                 const float rr = sigmoidf_(ar);
                 const float zz = sigmoidf_(az);
-                const float nn = tanhf(fmaf(rr, gh, gin[r]));
+                const float nn = tanhf_(fmaf(rr, gh, gin[r]));
                 const float hn = fmaf(zz, hprev[r] - nn, nn);
                 hprev[r] = hn;
                 hw[u * TS + c] = hn;
