@@ -139,3 +139,32 @@ def test_two_rank_gradient_allreduce_gloo():
         y.square().sum().backward()
         gs.append(torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.grad is not None]).numpy())
     np.testing.assert_allclose(g0, 0.5 * (gs[0] + gs[1]), rtol=1e-5, atol=1e-6)
+
+
+def test_checkpoint_round_trip_with_reference_layout(tmp_path):
+    """train.py:155-162 checkpoints ({'iter','model_state_dict','optimizer_state_dict','training_time_seconds'} as
+    '<iter>.pkl') load both ways between the reference layout (oracle modules = the reference's own block classes in the
+    R1 composition) and the HIP-backed modules: same 177 keys, same shapes, strict load; util.find_max_epoch finds it."""
+    from oracle import network_ref as nr, weights as W
+    from tinyrecurrentunet_amd import network as hn, util
+    ref = W.fill_state_dict(nr.TRUNet(input_size=4), seed=21)
+    opt = torch.optim.AdamW(ref.parameters(), lr=4e-4)
+    path = tmp_path / "1200.pkl"
+    torch.save({"iter": 1200, "model_state_dict": ref.state_dict(), "optimizer_state_dict": opt.state_dict(),
+                "training_time_seconds": 12}, str(path))
+    assert util.find_max_epoch(str(tmp_path)) == 1200
+    ck = torch.load(str(path), map_location="cpu", weights_only=True)
+    ours = hn.TRUNet(input_size=4)                       # parameter containers only: no GPU needed to load / save
+    missing = ours.load_state_dict(ck["model_state_dict"], strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    sd = ours.state_dict()
+    assert len(sd) == 177 and list(sd) == list(ref.state_dict())
+    for k, v in ref.state_dict().items():
+        assert torch.equal(sd[k], v), k
+    # and back: a checkpoint written from our module loads into the reference layout
+    torch.save({"iter": 1, "model_state_dict": ours.state_dict()}, str(tmp_path / "1.pkl"))
+    back = nr.TRUNet(input_size=4)
+    back.load_state_dict(torch.load(str(tmp_path / "1.pkl"), map_location="cpu", weights_only=True)["model_state_dict"])
+    assert W.checksum(back) == W.checksum(ref)
+    # the use_tgru extension does not change the parameter set
+    assert list(hn.TRUNet(input_size=4, use_tgru=True).state_dict()) == list(sd)
