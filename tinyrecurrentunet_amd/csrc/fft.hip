@@ -102,19 +102,39 @@ __global__ __launch_bounds__(256) void stft_features_kernel(const float* __restr
 }
 
 // PCEN (dataset.py:56-76): M[0] = s x[0]; M[t] = (1-s) M[t-1] + s x[t]; (x/(M+eps)^alpha + delta)^r - delta^r
-__global__ void pcen_kernel(const float* __restrict__ mag, float* __restrict__ out, int T, int out_stride, float eps,
-                            float s, float alpha, float delta, float r) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+// Block = (utterance b, 64 bins), 256 threads.  The smoother M is a cheap sequential scan over T (one wave, 2 flops per
+// step); the three powf per element are not part of the recurrence, so they run on all four waves over the chunk of
+// 256 time steps whose x and M the scan has just left in LDS.
+constexpr int PCEN_TC = 256;
+__global__ __launch_bounds__(256) void pcen_kernel(const float* __restrict__ mag, float* __restrict__ out, int T,
+                                                   int out_stride, float eps, float s, float alpha, float delta, float r) {
+    __shared__ float xs[PCEN_TC][64];
+    __shared__ float ms[PCEN_TC][64];
+    const int tid = threadIdx.x;
+    const int kb = blockIdx.x * 64;
     const int b = blockIdx.y;
-    if (k >= BINS) return;
-    const float* x = mag + (size_t)b * T * BINS + k;
-    float* o = out + (size_t)b * T * out_stride + k;
+    const float* x = mag + (size_t)b * T * BINS;
+    float* o = out + (size_t)b * T * out_stride;
     const float dr = powf(delta, r);
-    float M = 0.f;
-    for (int t = 0; t < T; ++t) {
-        const float v = x[(size_t)t * BINS];
-        M = (t == 0) ? s * v : (1.f - s) * M + s * v;
-        o[(size_t)t * out_stride] = powf(v / powf(M + eps, alpha) + delta, r) - dr;
+    float M = 0.f;                          // carried by threads 0..63 (bin kb + tid)
+    for (int t0 = 0; t0 < T; t0 += PCEN_TC) {
+        const int tc = min(PCEN_TC, T - t0);
+        if (tid < 64 && kb + tid < BINS) {
+#pragma unroll 4
+            for (int t = 0; t < tc; ++t) {
+                const float v = x[(size_t)(t0 + t) * BINS + kb + tid];
+                M = (t0 + t == 0) ? s * v : (1.f - s) * M + s * v;
+                xs[t][tid] = v;
+                ms[t][tid] = M;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < tc * 64; i += 256) {
+            const int t = i >> 6, k = i & 63;
+            if (kb + k < BINS)
+                o[(size_t)(t0 + t) * out_stride + kb + k] = powf(xs[t][k] / powf(ms[t][k] + eps, alpha) + delta, r) - dr;
+        }
+        __syncthreads();
     }
 }
 
@@ -449,7 +469,7 @@ extern "C" int trunet_stft_features(const float* audio, float* feat, float* mag,
 extern "C" int trunet_pcen(const float* mag, float* out, int B, int T, int out_stride, float eps, float s, float alpha,
                            float delta, float r, void* stream) {
     if (!mag || !out || B <= 0 || T <= 0) return TRUNET_EINVAL;
-    hipLaunchKernelGGL(pcen_kernel, dim3((BINS + 63) / 64, B), dim3(64), 0, ST, mag, out, T, out_stride, eps, s, alpha, delta, r);
+    hipLaunchKernelGGL(pcen_kernel, dim3((BINS + 63) / 64, B), dim3(256), 0, ST, mag, out, T, out_stride, eps, s, alpha, delta, r);
     return trunet_launch_status();
 }
 
