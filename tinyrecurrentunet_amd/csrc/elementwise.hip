@@ -473,12 +473,28 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     p[i] = pi - (lr / bc1) * (mi / denom);
 }
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* out) {
-    __shared__ double red[256];
-    double s = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 256) s += (double)g[i] * (double)g[i];
-    s = block_sum_f64(s, red);
-    if (threadIdx.x == 0) out[0] = (float)s;
+// one block (the caller passes no scratch for a second stage): 1024 threads, 16-byte loads, four independent chains
+__global__ __launch_bounds__(1024) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* out) {
+    __shared__ double red[1024];
+    const int tid = threadIdx.x;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const int64_t n4 = ((reinterpret_cast<uintptr_t>(g) & 15) == 0) ? n / 4 : 0;
+    const f32x4* g4 = (const f32x4*)g;
+    for (int64_t i = tid; i < n4; i += 1024) {
+        const f32x4 v = g4[i];
+        s0 += (double)v[0] * (double)v[0];
+        s1 += (double)v[1] * (double)v[1];
+        s2 += (double)v[2] * (double)v[2];
+        s3 += (double)v[3] * (double)v[3];
+    }
+    for (int64_t i = 4 * n4 + tid; i < n; i += 1024) s0 += (double)g[i] * (double)g[i];
+    red[tid] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if (tid < w) red[tid] += red[tid + w];
+        __syncthreads();
+    }
+    if (tid == 0) out[0] = (float)red[0];
 }
 
 }  // namespace
@@ -634,7 +650,7 @@ extern "C" int trunet_adamw(float* p, const float* g, float* m, float* v, int64_
 
 extern "C" int trunet_sumsq(const float* g, int64_t n, float* out, void* stream) {
     if (!g || !out || n <= 0) return TRUNET_EINVAL;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(256), 0, ST, g, n, out);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(1024), 0, ST, g, n, out);
     return trunet_launch_status();
 }
 
