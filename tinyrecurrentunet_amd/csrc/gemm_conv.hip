@@ -95,10 +95,11 @@ __global__ __launch_bounds__(64 * NW, (EPL == 0 || NW == 8) ? 2 : 1) void conv_g
             const int kk = 4 * kg + j;
             const int ci = cc * KC + 2 * kk + (ln >> 5);
             const int m = mblk * MB + 32 * rr + (ln & 31);
-            float v = 0.f;
-            if (ci < a.seg[s].nchan && m < a.M)
-                v = a.W[(size_t)(m + a.w_m_off) * a.ldw_m + (size_t)ci * a.ldw_c + a.seg[s].woff];
-            A_lds[idx] = v;
+            // branch-free (clamped address, then select): the compiler otherwise waits for every load before the next
+            const bool ok = ci < a.seg[s].nchan && m < a.M;
+            const float v = a.W[(size_t)(min(m, a.M - 1) + a.w_m_off) * a.ldw_m +
+                                (size_t)min(ci, a.seg[s].nchan - 1) * a.ldw_c + a.seg[s].woff];
+            A_lds[idx] = ok ? v : 0.f;
         }
         int base = 0;
         for (int s = 0; s < a.nseg; ++s) {
