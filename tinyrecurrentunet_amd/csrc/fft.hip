@@ -103,8 +103,8 @@ __global__ __launch_bounds__(256) void stft_features_kernel(const float* __restr
 
 // PCEN (dataset.py:56-76): M[0] = s x[0]; M[t] = (1-s) M[t-1] + s x[t]; (x/(M+eps)^alpha + delta)^r - delta^r
 // Block = (utterance b, 64 bins), 256 threads.  The smoother M is a cheap sequential scan over T (one wave, 2 flops per
-// step); the three powf per element are not part of the recurrence, so they run on all four waves over the chunk of
-// 256 time steps whose x and M the scan has just left in LDS.
+// step, from LDS); the loads and the three powf per element are not part of the recurrence, so they run on all four
+// waves over chunks of 256 time steps.
 constexpr int PCEN_TC = 256;
 __global__ __launch_bounds__(256) void pcen_kernel(const float* __restrict__ mag, float* __restrict__ out, int T,
                                                    int out_stride, float eps, float s, float alpha, float delta, float r) {
@@ -119,12 +119,15 @@ __global__ __launch_bounds__(256) void pcen_kernel(const float* __restrict__ mag
     float M = 0.f;                          // carried by threads 0..63 (bin kb + tid)
     for (int t0 = 0; t0 < T; t0 += PCEN_TC) {
         const int tc = min(PCEN_TC, T - t0);
-        if (tid < 64 && kb + tid < BINS) {
-#pragma unroll 4
+        for (int i = tid; i < tc * 64; i += 256) {          // the chunk's magnitudes: all threads, independent loads
+            const int t = i >> 6, k = i & 63;
+            xs[t][k] = (kb + k < BINS) ? x[(size_t)(t0 + t) * BINS + kb + k] : 0.f;
+        }
+        __syncthreads();
+        if (tid < 64) {                                      // the smoother: sequential over t, from LDS
             for (int t = 0; t < tc; ++t) {
-                const float v = x[(size_t)(t0 + t) * BINS + kb + tid];
+                const float v = xs[t][tid];
                 M = (t0 + t == 0) ? s * v : (1.f - s) * M + s * v;
-                xs[t][tid] = v;
                 ms[t][tid] = M;
             }
         }
