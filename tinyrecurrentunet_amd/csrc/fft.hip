@@ -102,43 +102,52 @@ __global__ __launch_bounds__(256) void stft_features_kernel(const float* __restr
 }
 
 // PCEN (dataset.py:56-76): M[0] = s x[0]; M[t] = (1-s) M[t-1] + s x[t]; (x/(M+eps)^alpha + delta)^r - delta^r
-// Block = (utterance b, 64 bins), 256 threads.  The smoother M is a cheap sequential scan over T (one wave, 2 flops per
-// step, from LDS); the loads and the three powf per element are not part of the recurrence, so they run on all four
-// waves over chunks of 256 time steps.
+// Two launches.  pcen_scan_kernel: block = (utterance b, 64 bins); the smoother M is a cheap sequential scan over T (one
+// wave, from LDS chunks that all four waves load) and is written into the OUTPUT slots.  pcen_pow_kernel: the three powf
+// per element are not part of the recurrence: one thread per (b, t, bin) replaces M by the result in place.
 constexpr int PCEN_TC = 256;
-__global__ __launch_bounds__(256) void pcen_kernel(const float* __restrict__ mag, float* __restrict__ out, int T,
-                                                   int out_stride, float eps, float s, float alpha, float delta, float r) {
+__global__ __launch_bounds__(256) void pcen_scan_kernel(const float* __restrict__ mag, float* __restrict__ out, int T,
+                                                        int out_stride, float s) {
     __shared__ float xs[PCEN_TC][64];
-    __shared__ float ms[PCEN_TC][64];
     const int tid = threadIdx.x;
     const int kb = blockIdx.x * 64;
     const int b = blockIdx.y;
     const float* x = mag + (size_t)b * T * BINS;
     float* o = out + (size_t)b * T * out_stride;
-    const float dr = powf(delta, r);
     float M = 0.f;                          // carried by threads 0..63 (bin kb + tid)
     for (int t0 = 0; t0 < T; t0 += PCEN_TC) {
         const int tc = min(PCEN_TC, T - t0);
-        for (int i = tid; i < tc * 64; i += 256) {          // the chunk's magnitudes: all threads, independent loads
+        for (int i = tid; i < tc * 64; i += 256) {
             const int t = i >> 6, k = i & 63;
             xs[t][k] = (kb + k < BINS) ? x[(size_t)(t0 + t) * BINS + kb + k] : 0.f;
         }
         __syncthreads();
-        if (tid < 64) {                                      // the smoother: sequential over t, from LDS
+        if (tid < 64) {
             for (int t = 0; t < tc; ++t) {
                 const float v = xs[t][tid];
                 M = (t0 + t == 0) ? s * v : (1.f - s) * M + s * v;
-                ms[t][tid] = M;
+                xs[t][tid] = M;
             }
         }
         __syncthreads();
         for (int i = tid; i < tc * 64; i += 256) {
             const int t = i >> 6, k = i & 63;
-            if (kb + k < BINS)
-                o[(size_t)(t0 + t) * out_stride + kb + k] = powf(xs[t][k] / powf(ms[t][k] + eps, alpha) + delta, r) - dr;
+            if (kb + k < BINS) o[(size_t)(t0 + t) * out_stride + kb + k] = xs[t][k];
         }
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(256) void pcen_pow_kernel(const float* __restrict__ mag, float* __restrict__ out, int rows,
+                                                       int out_stride, float eps, float alpha, float delta, float r,
+                                                       float dr) {
+    const int k = blockIdx.x * 256 + threadIdx.x;      // bin
+    const int row = blockIdx.y;                        // b*T + t
+    if (k >= BINS || row >= rows) return;
+    const float v = mag[(size_t)row * BINS + k];
+    float* o = out + (size_t)row * out_stride + k;
+    const float M = *o;
+    *o = powf(v / powf(M + eps, alpha) + delta, r) - dr;
 }
 
 // ---------------------------------------------------------------- mask + iSTFT
@@ -472,7 +481,9 @@ extern "C" int trunet_stft_features(const float* audio, float* feat, float* mag,
 extern "C" int trunet_pcen(const float* mag, float* out, int B, int T, int out_stride, float eps, float s, float alpha,
                            float delta, float r, void* stream) {
     if (!mag || !out || B <= 0 || T <= 0) return TRUNET_EINVAL;
-    hipLaunchKernelGGL(pcen_kernel, dim3((BINS + 63) / 64, B), dim3(256), 0, ST, mag, out, T, out_stride, eps, s, alpha, delta, r);
+    hipLaunchKernelGGL(pcen_scan_kernel, dim3((BINS + 63) / 64, B), dim3(256), 0, ST, mag, out, T, out_stride, s);
+    hipLaunchKernelGGL(pcen_pow_kernel, dim3((BINS + 255) / 256, B * T), dim3(256), 0, ST, mag, out, B * T, out_stride, eps,
+                       alpha, delta, r, powf(delta, r));
     return trunet_launch_status();
 }
 
