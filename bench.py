@@ -158,13 +158,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    # rehearsal of the multi-rank control flow on a one-GPU box: TRUNET_BENCH_ONE_DEVICE=1 puts every rank on cuda:0
+    # and TRUNET_BENCH_BACKEND=gloo replaces RCCL (which needs one GPU per rank); never used for reported numbers
+    if os.environ.get("TRUNET_BENCH_ONE_DEVICE"):
+        local = 0
+    backend = os.environ.get("TRUNET_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from tinyrecurrentunet_amd import distributed as tdist, engine, network as hn, optim, stft_loss as sl, util
     if args.streaming:
@@ -216,13 +224,15 @@ def main():
     value = total_frames / (dt / args.steps)
 
     roof = None
+    # per-kernel timing of one more step with HIP events on the launch stream (torch's current stream).  EVERY rank runs
+    # the step (it contains the gradient all-reduce); only rank 0 instruments it.
     if rank == 0:
-        # per-kernel timing of one more step with HIP events on the launch stream (torch's current stream)
         engine.PROFILE = prof = {}
         if os.environ.get("TRUNET_BENCH_LAUNCH_LOG"):
             engine.PROFILE_LOG = []
-        step()
-        torch.cuda.synchronize()
+    step()
+    sync()
+    if rank == 0:
         engine.PROFILE = None
         if engine.PROFILE_LOG is not None:
             with open(os.environ["TRUNET_BENCH_LAUNCH_LOG"], "w") as f:

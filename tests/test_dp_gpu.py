@@ -69,3 +69,25 @@ def test_two_rank_dp_step_matches_mean_of_local_gradients():
     for rank, err, n, tgru_none in res:
         assert n == 298592 and tgru_none
         assert err < 1e-5, (rank, err)
+
+
+def test_bench_two_ranks_complete_without_deadlock():
+    """bench.py under torch.distributed.run with 2 ranks (both on cuda:0, gloo instead of RCCL: this box has one GPU).
+    Guards the control flow of the multi-GPU benchmark: every rank must take part in every step that contains the
+    gradient all-reduce, including the instrumented one after the timed region."""
+    import json
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, TRUNET_BENCH_ONE_DEVICE="1", TRUNET_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--batch", "4", "--seconds", "1"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 8 and res["value"] > 0
+    assert res["roofline"] is not None and res["cpu_baseline"] is None
