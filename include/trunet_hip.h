@@ -11,7 +11,8 @@
  *   - all arithmetic is fp32 ("f32"); BatchNorm statistics are reduced in fp64.
  *
  * Internal activation layout ("frames-last"): a tensor of C channels x L positions for N frames
- * is stored as float[C][L][NP] with NP = N rounded up to a multiple of 128; element
+ * is stored as float[C][L][NP] with NP = N rounded up to a multiple of 128 (the host engine pads to 256, the widest
+ * conv_gemm tile); element
  * (c,l,n) lives at ((c*L + l)*NP + n).  Frames (the batch axis of network.py) are the contiguous
  * axis, so every conv tap / stride / pad / crop of network.py becomes a whole-row offset.
  */
@@ -155,11 +156,12 @@ int trunet_reduce_partials(float* out, const float* partials, int nparts, int nu
 /* BatchNorm1d training statistics -> affine (network.py:31,39,51,65,72 ...; torch semantics:
  * biased variance for normalisation, unbiased for running_var, momentum 0.1, eps 1e-5).
  * partials: [nparts][C][2] = sum, sumsq.  Writes scale = gamma*rstd, shift = beta - mean*scale,
- * mean, rstd; updates running_mean / running_var in place when non-NULL. */
+ * mean, rstd; updates running_mean / running_var in place when non-NULL and adds 1 to the int64 counter
+ * num_batches_tracked (BatchNorm1d's buffer) when non-NULL. */
 int trunet_bn_finalize_fwd(const float* partials, int nparts, int C, double count, const float* gamma,
                            const float* beta, float eps, float momentum, float* running_mean,
                            float* running_var, float* scale, float* shift, float* mean, float* rstd,
-                           void* stream);
+                           int64_t* num_batches_tracked, void* stream);
 /* eval mode: scale/shift from running statistics */
 int trunet_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean,
                           const float* running_var, float eps, float* scale, float* shift, void* stream);
@@ -168,6 +170,14 @@ int trunet_bn_eval_affine(int C, const float* gamma, const float* beta, const fl
 int trunet_bn_finalize_bwd(const float* partials, int nparts, int C, double count, const float* gamma,
                            const float* mean, const float* rstd, float* dgamma, float* dbeta, float* ca,
                            float* cb, float* cc, void* stream);
+
+/* ReLU / BatchNorm+ReLU backward at a block boundary (the stand-alone block classes of network.py:9-120 receive the
+ * cotangent of their post-activation output): dy[C][L][NP] *= [scale[c] z + shift[c] > 0] in place (scale == shift == NULL:
+ * [z > 0], network.py:14) for frames < N, 0 beyond; with mean/partials non-NULL also the BatchNorm-backward sums
+ * partials[trunet_relu_bwd_stats_nparts()][C][2] = sum dy, sum dy (z - mean[c]) for trunet_bn_finalize_bwd. */
+int trunet_relu_bwd_stats_nparts(void);
+int trunet_relu_bwd_stats(float* dy, const float* z, const float* scale, const float* shift, const float* mean,
+                          float* partials, int C, int L, int NP, int N, void* stream);
 
 /* (N,C,L) <-> frames-last [C][L][NP] (zero-fills frames >= N) */
 int trunet_to_frames_last(const float* x_ncl, float* y_clnp, int N, int C, int L, int NP, void* stream);
@@ -272,7 +282,8 @@ int trunet_l1_grad(const float* den, const float* clean, const float* scale, flo
 int trunet_reduce_cols(const float* partials, int nparts, int ncols, float* out, void* stream);
 /* One resolution of MultiResolutionSTFTLoss (stft_loss.py:9-113): win = Hann(win_length) zero-padded to n,
  * frames = 1 + L/hop.  fwd: partials[(b*frames + f)][3] = sum (|Y|-|X|)^2, sum |Y|^2, sum |log|Y| - log|X||
- * with |.| = sqrt(clamp(re^2+im^2, 1e-7)).  bwd: atomically adds d loss / d x into gx (B, L) given
+ * with |.| = sqrt(clamp(re^2+im^2, 1e-7)).  bwd (legacy form, float atomics: gx must be zero-filled; the engine uses
+ * trunet_stft_loss_bwd_gather below, which has none): adds d loss / d x into gx (B, L) given
  * coef[0] = g_sc*lambda_sc/(nres*sqrt(S1)*sqrt(S2)), coef[1] = g_mag*lambda_mag/(nres*count). */
 int trunet_stft_loss_fwd(const float* x, const float* y, const float* win, const float* tw, float* partials,
                          int B, int L, int n, int hop, void* stream);

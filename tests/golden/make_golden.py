@@ -98,9 +98,11 @@ def save(name, **arrs):
     print("wrote %-28s %7.1f KB" % (name, os.path.getsize(os.path.join(HERE, name + ".npz")) / 1024))
 
 
-def gen_blocks(ref):
+def gen_blocks(ref, only=None):
     rn = ref.net
     specs = {
+        # the unidirectional class of network.py:150 (TGRU), stand-alone: 3 sequences of 7 steps
+        "gru_uni": (rn.GRUBlock(64, 128, 64, False), [(3, 7, 64)]),
         "std": (rn.StandardConv1d(4, 64, 5, 2), [(2, 4, 257)]),
         "dsc_k3s1": (rn.DepthwiseSeparableConv1d(64, 128, 3, 1), [(2, 64, 32)]),
         "dsc_k5s2": (rn.DepthwiseSeparableConv1d(128, 128, 5, 2), [(2, 128, 32)]),
@@ -112,6 +114,8 @@ def gen_blocks(ref):
         "last_tr": (rn.LastTrCNN(128, 8, 5, 2), [(2, 64, 130), (2, 64, 128)]),
     }
     for name, (mod, shapes) in specs.items():
+        if only and name not in only:
+            continue
         W.fill_state_dict(mod, seed=11)
         wsum = W.checksum(mod)
         ins = [rnd(s, 100 + i) for i, s in enumerate(shapes)]
@@ -207,6 +211,9 @@ def gen_sched(ref):
 if __name__ == "__main__":
     torch.manual_seed(0)
     ref = load_reference()
+    if len(sys.argv) > 1:               # python tests/golden/make_golden.py block:gru_uni ...  (add single fixtures)
+        gen_blocks(ref, only=[a.split(":", 1)[1] for a in sys.argv[1:] if a.startswith("block:")])
+        sys.exit(0)
     gen_blocks(ref)
     gen_composition(ref)
     gen_stft_loss(ref)

@@ -130,6 +130,7 @@ BLOCKS = {
     "dsc_k5s2": ("DepthwiseSeparableConv1d", (128, 128, 5, 2)),
     "dsc_k3s2": ("DepthwiseSeparableConv1d", (128, 128, 3, 2)),
     "gru_bi": ("GRUBlock", (128, 64, 64, True)),
+    "gru_uni": ("GRUBlock", (64, 128, 64, False)),
     "first_tr": ("FirstTrCNN", (64, 64, 3, 2)),
     "tr_k5s2": ("TrCNN", (192, 64, 5, 2)),
     "tr_k3s1": ("TrCNN", (192, 64, 3, 1)),
@@ -156,6 +157,152 @@ def test_block_forward_matches_reference_golden(golden, name):
     for bn_, b in mod.named_buffers():
         if b.is_floating_point():
             assert _rel(b, torch.tensor(g["buf:" + bn_])) < 1e-4, bn_
+
+
+def _zero_grad_biases(mod):
+    """names of conv biases that sit directly in front of a BatchNorm: their gradient is analytically zero (the
+    BatchNorm subtracts the mean), so the reference holds rounding noise there and there is nothing to compare"""
+    out = set()
+    for mn, m in mod.named_modules():
+        if isinstance(m, torch.nn.Sequential):
+            for i in range(len(m) - 1):
+                if isinstance(m[i + 1], torch.nn.BatchNorm1d) and getattr(m[i], "bias", None) is not None:
+                    out.add((mn + "." if mn else "") + "%d.bias" % i)
+    return out
+
+
+def _tight(g, ref, name, tol, zero=(), outliers=0.0):
+    """Relative L2 AND max-abs error, both relative to the tensor's own scale (no absolute floor).
+    ``outliers``: fraction of elements left out of both bounds (largest errors first).  An fp32 and an fp64 run of a
+    ReLU network disagree on the mask of the few pre-activations that lie within rounding error of zero (about one in
+    1e6-1e7); each such flip changes an O(1) gradient contribution and spreads over the ~100 data-gradient elements
+    that share the position.  Only data gradients of the large-N tests use it; a dropped tap, a wrong offset or a
+    missing share of a sum moves (nearly) every element and is not masked by it."""
+    g, ref = g.detach().double().cpu(), torch.as_tensor(ref).double()
+    scale = float(ref.abs().max())
+    if name in zero:
+        # rounding noise of a sum of ~N*L O(1) terms that cancels exactly (fp32 partial sums of magnitude ~N*L)
+        assert float(g.abs().max()) < 2e-2 and scale < 2e-2, (name, float(g.abs().max()), scale)
+        return
+    d = (g - ref).abs().reshape(-1)
+    if outliers > 0:
+        k = d.numel() - int(outliers * d.numel())
+        d = torch.topk(d, k, largest=False).values
+    assert float(d.norm() / ref.norm()) < tol, (name, "L2", float(d.norm() / ref.norm()))
+    assert float(d.max()) < 3 * tol * scale, (name, "max", float(d.max()), scale)
+
+
+@pytest.mark.parametrize("name", sorted(BLOCKS))
+def test_block_backward_matches_reference_golden(golden, name):
+    """Backward of every stand-alone block class on the HIP path (the same launches the fused TRUNet schedule uses for
+    that block: dwconv_bwd, gru_bwd / tgru_rec_bwd, transposed-conv dgrad + wgrad on tap segments with crop / pad,
+    pw_bwd, bn_finalize_bwd, conv_first wgrad) against gradients produced by the REFERENCE's own classes
+    (network.py:9-120 under torch autograd, tests/golden/make_golden.py): input gradients gx*, every parameter
+    gradient g:*.  Two or three frames only, so the sums are short and well conditioned: bound 1e-3 relative."""
+    from oracle import weights as W
+    from tinyrecurrentunet_amd import network as hn
+    g = golden("block_" + name)
+    cls, args = BLOCKS[name]
+    mod = getattr(hn, cls)(*args)
+    W.fill_state_dict(mod, seed=11)
+    mod.cuda().train()
+    ins = [torch.tensor(g["x%d" % i]).cuda().requires_grad_(True) for i in range(2) if "x%d" % i in g]
+    y = mod(*ins)
+    assert _rel(y, torch.tensor(g["y_train"])) < 1e-4
+    (y * torch.tensor(g["cot"]).cuda()).sum().backward()
+    torch.cuda.synchronize()
+    zero = _zero_grad_biases(mod)
+    assert len(zero) == {"std": 0, "last_tr": 1, "gru_bi": 1, "gru_uni": 1}.get(name, 2)
+    for i, x in enumerate(ins):
+        assert x.grad is not None
+        _tight(x.grad, g["gx%d" % i], "gx%d" % i, 1e-3)
+    for pn, p in mod.named_parameters():
+        assert p.grad is not None, pn
+        _tight(p.grad, g["g:" + pn], pn, 1e-3, zero)
+
+
+BLOCK_SHAPES = {   # input shapes per frame count N (the shapes these classes see inside TRUNet)
+    "std": lambda N: [(N, 4, 257)],
+    "dsc_k3s1": lambda N: [(N, 64, 32)],
+    "dsc_k5s2": lambda N: [(N, 128, 31)],
+    "dsc_k3s2": lambda N: [(N, 128, 32)],
+    "gru_bi": lambda N: [(N, 16, 128)],
+    "gru_uni": lambda N: [(N // 9, 9, 64)],
+    "first_tr": lambda N: [(N, 64, 16)],
+    "tr_k5s2": lambda N: [(N, 64, 31), (N, 128, 32)],      # F.pad by one on the left (decoder.1)
+    "tr_k3s1": lambda N: [(N, 64, 66), (N, 128, 64)],      # crop one on each side (decoder.3's input, network.py:96-97)
+    "last_tr": lambda N: [(N, 64, 130), (N, 64, 128)],
+}
+
+
+@pytest.mark.parametrize("N", [300, 777])
+@pytest.mark.parametrize("name", sorted(BLOCKS))
+def test_block_backward_vs_oracle_f64(name, N):
+    """Per-block backward at frame counts that span several tiles / partial rows and are not multiples of the tile
+    width, against the fp64 oracle block (stock torch layers under autograd in double precision): every kernel of the
+    backward schedule is pinned here on its own, with a short dependency chain: dwconv_bwd (k3s1, k5s2, k3s2), gru_bwd,
+    tgru_rec_bwd, the transposed-conv data gradient / weight gradient launches on tap segments incl. F.pad and crop,
+    pw_bwd, conv_first, relu_bwd_stats + bn_finalize_bwd.  Bounds, scaled to each tensor (no absolute floor): data
+    gradients 2e-4 relative L2 outside the 1e-3 of elements hit by ReLU-mask flips (see _tight), parameter gradients
+    1e-3 relative L2 and 3e-3 of max|g| per element (measured 2e-5 ... 8e-4; the whole-network bound was 6e-2)."""
+    from oracle import network_ref as nr, weights as W
+    from tinyrecurrentunet_amd import network as hn
+    cls, args = BLOCKS[name]
+    mod = W.fill_state_dict(getattr(hn, cls)(*args), seed=13).cuda().train()
+    ref = W.fill_state_dict(getattr(nr, cls)(*args), seed=13).double().train()
+    rng = np.random.default_rng(N + len(name))
+    shapes = BLOCK_SHAPES[name](N)
+    xs = [torch.tensor(rng.standard_normal(s) * 0.7, dtype=torch.float32) for s in shapes]
+    xg = [x.cuda().requires_grad_(True) for x in xs]
+    xd = [x.double().requires_grad_(True) for x in xs]
+    y = mod(*xg)
+    yd = ref(*xd)
+    assert _rel(y, yd) < 1e-5
+    cot = torch.tensor(rng.standard_normal(tuple(yd.shape)), dtype=torch.float32)
+    (y * cot.cuda()).sum().backward()
+    (yd * cot.double()).sum().backward()
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(xg, xd)):
+        _tight(a.grad, b.grad, "gx%d" % i, 2e-4, outliers=1e-3)
+    pd = dict(ref.named_parameters())
+    zero = _zero_grad_biases(mod)
+    for pn, p in mod.named_parameters():
+        _tight(p.grad, pd[pn].grad, pn, 1e-3, zero)      # a single mask flip moves a weight gradient by ~3e-4 of its norm
+    for bn_, b in mod.named_buffers():
+        if b.is_floating_point():
+            assert _rel(b, dict(ref.named_buffers())[bn_]) < 1e-5, bn_
+
+
+def test_saved_activations_are_guarded():
+    """activations saved for backward live in the engine's workspace.  A no_grad / eval forward between
+    forward and backward must not disturb them (it runs in its own workspace); a second recording forward before the
+    first backward must fail loudly instead of returning wrong gradients."""
+    from tinyrecurrentunet_amd import _lib
+    _, net = _nets(4, seed=5)
+    net.train()
+    x = torch.tensor(np.random.default_rng(0).standard_normal((40, 4, 257)) * 0.5, dtype=torch.float32).cuda()
+    x2 = torch.tensor(np.random.default_rng(1).standard_normal((40, 4, 257)) * 0.5, dtype=torch.float32).cuda()
+    cot = torch.tensor(np.random.default_rng(2).standard_normal((40, 8, 257)), dtype=torch.float32).cuda()
+    y = net(x)
+    (y * cot).sum().backward()
+    ref = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    net.zero_grad()
+    # BatchNorm running statistics moved in the first pass: reload so both passes see identical buffers
+    _, net2 = _nets(4, seed=5)
+    net2.train()
+    y = net2(x)
+    with torch.no_grad():
+        net2(x2)                               # same padded frame count, would overwrite z:* in a shared workspace
+        net2.eval(); net2(x2[:1]); net2.train()
+    (y * cot).sum().backward()
+    for n, p in net2.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(p.grad, ref[n]), n
+    y1 = net2(x)
+    y2 = net2(x2)                              # second recording forward before the first backward
+    with pytest.raises(_lib.TrunetHipError):
+        (y1 * cot).sum().backward()
+    (y2 * cot).sum().backward()                # the most recent forward is intact
 
 
 def test_tgru_streaming_matches_oracle():

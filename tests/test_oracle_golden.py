@@ -14,6 +14,7 @@ BLOCKS = {
     "dsc_k5s2": lambda: nr.DepthwiseSeparableConv1d(128, 128, 5, 2),
     "dsc_k3s2": lambda: nr.DepthwiseSeparableConv1d(128, 128, 3, 2),
     "gru_bi": lambda: nr.GRUBlock(128, 64, 64, True),
+    "gru_uni": lambda: nr.GRUBlock(64, 128, 64, False),
     "first_tr": lambda: nr.FirstTrCNN(64, 64, 3, 2),
     "tr_k5s2": lambda: nr.TrCNN(192, 64, 5, 2),
     "tr_k3s1": lambda: nr.TrCNN(192, 64, 3, 1),

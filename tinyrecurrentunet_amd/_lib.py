@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libtrunet_hip.so")
 
 MAX_SEG = 5
+TRUNET_OK, TRUNET_EINVAL, TRUNET_ELAUNCH, TRUNET_ENOTSUP = 0, -1, -2, -3
 PRO_NONE, PRO_BNRELU, PRO_BNBWD = 0, 1, 2
 EPI_BIAS, EPI_STATS, EPI_ACCUM, EPI_MASK, EPI_RELU = 1, 2, 4, 8, 16
 
@@ -85,7 +86,9 @@ def _declare(L):
         "trunet_pw_bwd_nparts": [],
         "trunet_pw_bwd": [C.POINTER(PwBwdArgs), p],
         "trunet_reduce_partials": [p, p, i, i, i, p],
-        "trunet_bn_finalize_fwd": [p, i, i, d, p, p, f, f, p, p, p, p, p, p, p],
+        "trunet_bn_finalize_fwd": [p, i, i, d, p, p, f, f, p, p, p, p, p, p, p, p],
+        "trunet_relu_bwd_stats_nparts": [],
+        "trunet_relu_bwd_stats": [p, p, p, p, p, p, i, i, i, i, p],
         "trunet_bn_eval_affine": [i, p, p, p, p, f, p, p, p],
         "trunet_bn_finalize_bwd": [p, i, i, d, p, p, p, p, p, p, p, p, p],
         "trunet_to_frames_last": [p, p, i, i, i, i, p],

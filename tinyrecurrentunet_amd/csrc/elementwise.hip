@@ -208,6 +208,44 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(
     }
 }
 
+// ---------------------------------------------------------------- activation backward at a block boundary
+// A stand-alone block class (network.py:9-120) receives the cotangent of its POST-activation output, the fused
+// schedule works on gradients of the BatchNorm output: dy *= [sc[c] z + sh[c] > 0] in place (sc == NULL: [z > 0],
+// StandardConv1d's plain ReLU) and, with mean != NULL, the BatchNorm-backward sums of the result
+// (sum dy, sum dy (z - mean[c])) -> partials[DW_PARTS][C][2].
+__global__ __launch_bounds__(256) void relu_bwd_stats_kernel(float* __restrict__ dy, const float* __restrict__ z,
+                                                             const float* __restrict__ sc, const float* __restrict__ sh,
+                                                             const float* __restrict__ mean, float* __restrict__ partials,
+                                                             int C, int L, int NP, int N) {
+    __shared__ double red[256];
+    const int c = blockIdx.y;
+    const int f4 = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const float a0 = sc ? sc[c] : 1.f, a1 = sc ? sh[c] : 0.f, mu = mean ? mean[c] : 0.f;
+    const int ntn = NP / 128;
+    const int items = L * ntn;
+    float s1 = 0.f, s2 = 0.f;
+    for (int it = blockIdx.x * 8 + ly; it < items; it += gridDim.x * 8) {
+        const int nt = it / L, l = it - nt * L;
+        const int n = nt * 128 + 4 * f4;
+        const size_t off = ((size_t)c * L + l) * NP + n;
+        f32x4 d = *(const f32x4*)(dy + off);
+        const f32x4 zv = *(const f32x4*)(z + off);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            d[e] = (n + e < N && fmaf(zv[e], a0, a1) > 0.f) ? d[e] : 0.f;
+            s1 += d[e];
+            s2 = fmaf(d[e], (n + e < N) ? zv[e] - mu : 0.f, s2);
+        }
+        *(f32x4*)(dy + off) = d;
+    }
+    if (partials) {
+        double r = block_sum_f64((double)s1, red);
+        if (threadIdx.x == 0) partials[((size_t)blockIdx.x * C + c) * 2 + 0] = (float)r;
+        r = block_sum_f64((double)s2, red);
+        if (threadIdx.x == 0) partials[((size_t)blockIdx.x * C + c) * 2 + 1] = (float)r;
+    }
+}
+
 // ---------------------------------------------------------------- one GRU time step (streaming TGRU)
 // gi = W_ih x + b_ih, gh = W_hh h + b_hh as [3H][R] rows (R = L*NP contiguous), torch gate order r, z, n:
 //   r = sigmoid(gi_r + gh_r), z = sigmoid(gi_z + gh_z), n = tanh(gi_n + r * gh_n), h' = (1 - z) n + z h
@@ -395,7 +433,8 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __res
                                                               double count, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float eps, float momentum,
                                                               float* running_mean, float* running_var, float* scale,
-                                                              float* shift, float* mean_o, float* rstd_o) {
+                                                              float* shift, float* mean_o, float* rstd_o,
+                                                              long long* num_batches_tracked) {
     __shared__ double red[256];
     const int c = blockIdx.x;
     double a = 0.0, b = 0.0;
@@ -406,6 +445,7 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __res
     a = block_sum_f64(a, red);
     b = block_sum_f64(b, red);
     if (threadIdx.x == 0) {
+        if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;     // BatchNorm1d.num_batches_tracked (int64)
         double mean = a / count;
         double var = b / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -611,13 +651,25 @@ extern "C" int trunet_dwconv_bwd(const float* dy, const float* z, const float* c
     return trunet_launch_status();
 }
 
+extern "C" int trunet_relu_bwd_stats_nparts(void) { return DW_PARTS; }
+
+extern "C" int trunet_relu_bwd_stats(float* dy, const float* z, const float* scale, const float* shift, const float* mean,
+                                     float* partials, int C, int L, int NP, int N, void* stream) {
+    if (!dy || !z || C <= 0 || L <= 0 || N <= 0 || NP < N || (NP % 128)) return TRUNET_EINVAL;
+    if ((scale == nullptr) != (shift == nullptr) || (mean != nullptr) != (partials != nullptr)) return TRUNET_EINVAL;
+    hipLaunchKernelGGL(relu_bwd_stats_kernel, dim3(DW_PARTS, C), dim3(256), 0, ST, dy, z, scale, shift, mean, partials, C,
+                       L, NP, N);
+    return trunet_launch_status();
+}
+
 extern "C" int trunet_bn_finalize_fwd(const float* partials, int nparts, int C, double count, const float* gamma,
                                       const float* beta, float eps, float momentum, float* running_mean,
                                       float* running_var, float* scale, float* shift, float* mean, float* rstd,
-                                      void* stream) {
+                                      int64_t* num_batches_tracked, void* stream) {
     if (!partials || !gamma || !beta || !scale || !shift || !mean || !rstd || C <= 0 || nparts <= 0) return TRUNET_EINVAL;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return TRUNET_EINVAL;
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(C), dim3(256), 0, ST, partials, nparts, C, count, gamma, beta, eps,
-                       momentum, running_mean, running_var, scale, shift, mean, rstd);
+                       momentum, running_mean, running_var, scale, shift, mean, rstd, (long long*)num_batches_tracked);
     return trunet_launch_status();
 }
 

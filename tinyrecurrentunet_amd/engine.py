@@ -120,9 +120,14 @@ class Act:
 
 
 class Workspace:
+    """Name-keyed device buffers of one padded frame count.  Activations saved for backward live here too (they are the
+    forward's own buffers), so a workspace that RECORDS for backward carries a generation counter: every recording
+    forward bumps it, and ``backward`` refuses to run on buffers a later forward has overwritten."""
+
     def __init__(self, dev):
         self.dev = dev
         self.t = {}
+        self.gen = 0
 
     def get(self, name, shape, zero=False):
         t = self.t.get(name)
@@ -159,11 +164,23 @@ class TRUNetEngine:
         self._ws = {}
 
     # ------------------------------------------------------------------ helpers
-    def ws(self, NP, dev):
-        key = (NP, str(dev))
+    def ws(self, NP, dev, record=False):
+        """Workspace of (NP, device).  Forwards that record for backward and forwards that do not (no_grad / eval /
+        streaming) get separate workspaces, so a validation forward between ``loss = net(x)`` and ``loss.backward()``
+        cannot touch the saved activations; one size of each kind stays resident."""
+        key = (NP, str(dev), bool(record))
         if key not in self._ws:
-            self._ws = {key: Workspace(dev)}      # keep one size resident
+            self._ws = {k: v for k, v in self._ws.items() if k[2] != key[2]}
+            self._ws[key] = Workspace(dev)
         return self._ws[key]
+
+    @staticmethod
+    def _check_gen(w, gen):
+        if w.gen != gen:
+            raise L.TrunetHipError(
+                "backward() of a forward whose saved activations were overwritten: another gradient-recording forward of "
+                "the same module ran before this backward (forward #%d, workspace is at #%d).  Call backward() before "
+                "the next training forward (no_grad / eval forwards in between are fine)." % (gen, w.gen))
 
     def _gemm(self, w, *, N, NP, P, M, out, out_L, W, ldw_m, ldw_c, segs, p_begin=0, out_pos_off=0, m_out_off=0,
               w_m_off=0, epi=0, bias=None, zmask=None, e0=None, e1=None, e2=None, stats=None):
@@ -216,6 +233,11 @@ class TRUNetEngine:
         return a
 
     # ------------------------------------------------------------------ TGRU as a trained layer (use_tgru)
+    def _tgru_block(self):
+        """the GRUBlock(64, 128, 64, False) this engine runs over time: TRUNet.TGRU, or the module itself when the engine
+        belongs to a stand-alone GRUBlock"""
+        return getattr(self.net, "TGRU", self.net)
+
     def _tgru_seq_fwd(self, w, cur, N, NP, T, training, acts):
         """GRUBlock(64, 128, 64) of network.py:150 over TIME, between FGRU and the decoder (docs/net.jpg; SURVEY 8f
         rank 1): every (utterance, frequency position) is a sequence of T frames.  Sequence-major tensors [C][T][SP];
@@ -223,7 +245,7 @@ class TRUNetEngine:
         GEMM kernels, the recurrence itself is a host loop of (W_hh h GEMM, cell) pairs -- correct first; a persistent
         recurrent kernel is the next step."""
         lib, st = L.lib(), L.stream()
-        blk = self.net.TGRU
+        blk = self._tgru_block()
         gru = blk.GRU
         Hh, Lf, C = gru.hidden_size, cur.L, cur.C
         if gru.bidirectional or gru.input_size != C or T <= 0 or N % T:
@@ -233,8 +255,8 @@ class TRUNetEngine:
         S = B * Lf
         SP = ceil_to(S, FRAME_PAD)
         xs = w.get("tg.xs", (C, T, SP))
-        check(lib.trunet_to_seq_major(ptr(cur.t), ptr(xs), ptr(cur.bn.scale), ptr(cur.bn.shift), 1, C, Lf, T, B, NP, SP,
-                                      st), "to_seq_major")
+        sc, sh = (cur.bn.scale, cur.bn.shift) if cur.bn is not None else (None, None)     # raw source: stand-alone block
+        check(lib.trunet_to_seq_major(ptr(cur.t), ptr(xs), ptr(sc), ptr(sh), 1, C, Lf, T, B, NP, SP, st), "to_seq_major")
         gi = w.get("tg.gi", (3 * Hh, T, SP))
         persistent = Hh == 128 and not TGRU_LOOP
         b_in = gru.bias_ih_l0.data
@@ -281,7 +303,7 @@ class TRUNetEngine:
         lib, st = L.lib(), L.stream()
         c = acts["tgru.ctx"]
         xs, gi, hs, gates, zc, S, SP, T, B = (c[k] for k in ("xs", "gi", "hs", "gates", "zc", "S", "SP", "T", "B"))
-        blk = self.net.TGRU
+        blk = self._tgru_block()
         gru, conv = blk.GRU, blk.conv[0]
         Hh, Cc = gru.hidden_size, conv.out_channels
         src = acts["fgru"]
@@ -326,6 +348,10 @@ class TRUNetEngine:
         dyf = w.get("dy:fgru", (C, Lf, NP))
         if NP > N:
             dyf[:, :, N:].zero_()
+        if src.bn is None:       # raw source (stand-alone block): plain gradient of the block input
+            check(lib.trunet_from_seq_major(ptr(dxs), ptr(dyf), None, None, None, None, None, C, Lf, T, B, NP, SP, st),
+                  "from_seq_major")
+            return dyf, None, None
         nparts = lib.trunet_from_seq_major_nparts(Lf, T, B)
         part = w.flat("tg.partials", nparts * C * 2)
         check(lib.trunet_from_seq_major(ptr(dxs), ptr(dyf), ptr(src.t), ptr(src.bn.scale), ptr(src.bn.shift),
@@ -342,12 +368,11 @@ class TRUNetEngine:
             rm = module.running_mean if module.track_running_stats else None
             rv = module.running_var if module.track_running_stats else None
             mom = BN_MOM if module.momentum is None else module.momentum
+            nbt = module.num_batches_tracked.data_ptr() if module.track_running_stats else None
             check(lib.trunet_bn_finalize_fwd(ptr(part), nparts, C, float(count), ptr(module.weight.data),
                                              ptr(module.bias.data), module.eps, mom, ptr(rm), ptr(rv),
-                                             ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.rstd), L.stream()),
+                                             ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.rstd), nbt, L.stream()),
                   "bn_finalize_fwd")
-            if module.track_running_stats:
-                module.num_batches_tracked.add_(1)
         else:
             check(lib.trunet_bn_eval_affine(C, ptr(module.weight.data), ptr(module.bias.data),
                                             ptr(module.running_mean), ptr(module.running_var), module.eps,
@@ -401,18 +426,18 @@ class TRUNetEngine:
             rm = bn.running_mean if bn.track_running_stats else None
             rv = bn.running_var if bn.track_running_stats else None
             mom = BN_MOM if bn.momentum is None else bn.momentum
+            nbt = bn.num_batches_tracked.data_ptr() if bn.track_running_stats else None
             check(lib.trunet_bn_finalize_fwd(ptr(part), nparts, C, float(N * Lo), ptr(bn.weight.data),
                                              ptr(bn.bias.data), bn.eps, mom, ptr(rm), ptr(rv), ptr(st.scale),
-                                             ptr(st.shift), ptr(st.mean), ptr(st.rstd), L.stream()), "bn_finalize_fwd")
-            if bn.track_running_stats:
-                bn.num_batches_tracked.add_(1)
+                                             ptr(st.shift), ptr(st.mean), ptr(st.rstd), nbt, L.stream()), "bn_finalize_fwd")
         else:
             check(lib.trunet_bn_eval_affine(C, ptr(bn.weight.data), ptr(bn.bias.data), ptr(bn.running_mean),
                                             ptr(bn.running_var), bn.eps, ptr(st.scale), ptr(st.shift), L.stream()),
                   "bn_eval_affine")
         return Act(out, C, Lo, st)
 
-    # ------------------------------------------------------------------ stand-alone blocks (forward only)
+
+    # ------------------------------------------------------------------ stand-alone blocks (network.py:9-120)
     def _load(self, w, name, x):
         x = x.contiguous()
         N, C, Ln = x.shape
@@ -421,23 +446,27 @@ class TRUNetEngine:
         check(L.lib().trunet_to_frames_last(ptr(x), ptr(t), N, C, Ln, NP, L.stream()), "to_frames_last")
         return Act(t, C, Ln), N, NP
 
-    def _store(self, act, N, NP, dev):
+    def _store(self, act, N, NP, dev, relu=True):
         out = torch.empty((N, act.C, act.L), device=dev, dtype=torch.float32)
         if act.bn is None:
             check(L.lib().trunet_from_frames_last(ptr(act.t), ptr(out), N, act.C, act.L, NP, L.stream()), "from_frames_last")
         else:
             check(L.lib().trunet_from_frames_last_affine(ptr(act.t), ptr(out), N, act.C, act.L, NP, ptr(act.bn.scale),
-                                                         ptr(act.bn.shift), 1, L.stream()), "from_frames_last_affine")
+                                                         ptr(act.bn.shift), 1 if relu else 0, L.stream()),
+                  "from_frames_last_affine")
         return out
 
-    def block_forward(self, kind, seq, xs, training):
-        """Forward of one reference block class (network.py:9-120) on (N, C, L) tensors; returns the block's
-        post-activation output like the reference.  Forward only: training goes through ``TRUNet``."""
+    def block_forward(self, kind, seq, xs, training, record=False):
+        """Forward of one reference block class (network.py:9-120) on (N, C, L) tensors; returns (y, ctx) with y the
+        block's post-activation output like the reference and ctx what ``block_backward`` needs (record=True)."""
         dev = xs[0].device
         N = xs[0].shape[0]
         NP = ceil_to(N, FRAME_PAD)
-        w = self.ws(NP, dev)
+        w = self.ws(NP, dev, record)
+        if record:
+            w.gen += 1
         lib = L.lib()
+        acts = {}
         if kind == "std":
             a, N, NP = self._load(w, "b0", xs[0])
             conv = seq[0]
@@ -448,36 +477,134 @@ class TRUNetEngine:
             out = w.get("z:blk", (conv.out_channels, Lo, NP))
             check(lib.trunet_conv_first_fwd(ptr(a.t), ptr(conv.weight.data), ptr(conv.bias.data), ptr(out), a.C,
                                             conv.out_channels, k, s, a.L, Lo, NP, L.stream()), "conv_first_fwd")
-            return self._store(Act(out, conv.out_channels, Lo), N, NP, dev)
-        if kind == "dsc":
+            cur = Act(out, conv.out_channels, Lo)
+            acts.update(x=a, out=cur)
+        elif kind == "dsc":
             a, N, NP = self._load(w, "b0", xs[0])
-            cur = self._pw(w, "blk.pw", [a], seq[0], seq[1], N, NP, training)
-            cur = self._dw(w, "blk", cur, seq[3], seq[4], N, NP, training)
-            return self._store(cur, N, NP, dev)
-        if kind in ("first_tr", "tr", "last_tr"):
+            pw = self._pw(w, "blk.pw", [a], seq[0], seq[1], N, NP, training)
+            cur = self._dw(w, "blk", pw, seq[3], seq[4], N, NP, training)
+            acts.update(x=a, pw=pw, out=cur)
+        elif kind in ("first_tr", "tr", "last_tr"):
             a, N, NP = self._load(w, "b0", xs[0])
-            srcs, left = [a], 0
+            srcs, left, b = [a], 0, None
             if kind != "first_tr":
                 b, _, _ = self._load(w, "b1", xs[1])
                 left = (b.L - a.L) // 2
                 srcs = [a, b]
-            cur = self._pw(w, "blk.pw", srcs, seq[0], seq[1], N, NP, training, x1_left=left)
-            cur = self._convT(w, "blk", cur, seq[3], seq[4] if kind != "last_tr" else None, N, NP, training)
-            return self._store(cur, N, NP, dev)
-        raise ValueError(kind)
+            pw = self._pw(w, "blk.pw", srcs, seq[0], seq[1], N, NP, training, x1_left=left)
+            cur = self._convT(w, "blk", pw, seq[3], seq[4] if kind != "last_tr" else None, N, NP, training)
+            acts.update(x=a, x2=b, left=left, pw=pw, out=cur)
+        else:
+            raise ValueError(kind)
+        return self._store(cur, N, NP, dev), (kind, seq, acts, N, NP, w, w.gen)
 
-    def gru_block_forward(self, blk, x, training):
-        """GRUBlock.forward (network.py:54-58): x (N, L, C_in) -> (N, C_out, L)."""
+    def gru_block_forward(self, blk, x, training, record=False):
+        """GRUBlock.forward (network.py:54-58): x (S, L, C_in) -> (S, C_out, L).  bidirectional H=64: the FGRU kernels
+        (recurrence over the L positions of every frame); unidirectional H=128 (network.py:150's TGRU class): the
+        time-recurrent kernels with every row of x as one sequence."""
         gru = blk.GRU
-        if not gru.bidirectional or gru.hidden_size != 64:
-            raise L.TrunetHipError("the HIP GRU kernel is built for the bidirectional H=64 FGRU (network.py:149); "
-                                   "the unidirectional TGRU (network.py:150) is never executed (R4)")
         dev = x.device
-        a, N, NP = self._load(self.ws(ceil_to(x.shape[0], FRAME_PAD), dev), "b0", x.transpose(1, 2))
-        w = self.ws(NP, dev)
-        hout = self._gru(w, a, gru, N, NP, training)
-        cur = self._pw(w, "blk.fgru", [hout], blk.conv[0], blk.conv[1], N, NP, training)
-        return self._store(cur, N, NP, dev)
+        S, Lx, C = x.shape
+        if gru.bidirectional and gru.hidden_size == 64:
+            NP = ceil_to(S, FRAME_PAD)
+            w = self.ws(NP, dev, record)
+            if record:
+                w.gen += 1
+            a, N, NP = self._load(w, "b0", x.transpose(1, 2))
+            hout = self._gru(w, a, gru, N, NP, training)
+            cur = self._pw(w, "blk.fgru", [hout], blk.conv[0], blk.conv[1], N, NP, training)
+            acts = dict(x=a, hout=hout, out=cur)
+            return self._store(cur, N, NP, dev), ("gru_bi", blk, acts, N, NP, w, w.gen)
+        if not gru.bidirectional:
+            # frames-last with ONE position per frame: frame index s*T + t, so (s, position 0) is a sequence over t
+            N, T = S * Lx, Lx
+            NP = ceil_to(N, FRAME_PAD)
+            w = self.ws(NP, dev, record)
+            if record:
+                w.gen += 1
+            a, N, NP = self._load(w, "b0", x.reshape(N, C, 1))
+            acts = {"fgru": a}
+            cur = self._tgru_seq_fwd(w, a, N, NP, T, training, acts)
+            acts["out"] = cur
+            y = self._store(cur, N, NP, dev)                           # (S*T, C_out, 1)
+            return y.reshape(S, T, cur.C).transpose(1, 2).contiguous(), ("gru_uni", blk, acts, N, NP, w, w.gen)
+        raise L.TrunetHipError("the HIP GRU kernels are built for GRUBlock(128, 64, 64, True) (network.py:149) and "
+                               "GRUBlock(64, 128, 64, False) (network.py:150)")
+
+    def _entry(self, w, out, gout, N, NP, grads, relu=True):
+        """Cotangent of a block's post-activation output (N, C, L) -> upstream state (dy, z, bn) of the fused schedule:
+        dy = gradient at the BatchNorm output with the ReLU mask applied, plus the BatchNorm-backward reduction."""
+        lib, st = L.lib(), L.stream()
+        gout = gout.contiguous().float()
+        dyt = w.get("dy:blk", (out.C, out.L, NP))
+        check(lib.trunet_to_frames_last(ptr(gout), ptr(dyt), N, out.C, out.L, NP, st), "to_frames_last")
+        if out.bn is None:
+            if relu:
+                check(lib.trunet_relu_bwd_stats(ptr(dyt), ptr(out.t), None, None, None, None, out.C, out.L, NP, N, st),
+                      "relu_bwd_stats")
+            return dyt, out.t, None
+        nparts = lib.trunet_relu_bwd_stats_nparts()
+        part = w.flat("entry_partials", nparts * out.C * 2)
+        check(lib.trunet_relu_bwd_stats(ptr(dyt), ptr(out.t), ptr(out.bn.scale), ptr(out.bn.shift), ptr(out.bn.mean),
+                                        ptr(part), out.C, out.L, NP, N, st), "relu_bwd_stats")
+        self._bn_bwd(w, out.bn, nparts, grads, part_name="entry_partials")
+        return dyt, out.t, out.bn
+
+    def _unload(self, t, N, C, Ln, NP):
+        out = torch.empty((N, C, Ln), device=t.device, dtype=torch.float32)
+        check(L.lib().trunet_from_frames_last(ptr(t), ptr(out), N, C, Ln, NP, L.stream()), "from_frames_last")
+        return out
+
+    def block_backward(self, ctx, gout):
+        """Backward of block_forward / gru_block_forward: gout = cotangent of the block output.  Returns
+        ({parameter: gradient}, [gradient of each block input])."""
+        kind, seq, acts, N, NP, w, gen = ctx
+        self._check_gen(w, gen)
+        grads = {}
+        self._wg_begin(w)
+        out = acts["out"]
+        if kind == "gru_uni":
+            g = gout.transpose(1, 2).reshape(N, out.C, 1)
+            up = self._entry(w, out, g, N, NP, grads)
+            dyx, _, _ = self._tgru_seq_bwd(w, acts, up[0], up[2], N, NP, grads)
+            x = acts["fgru"]
+            gx = self._unload(dyx, N, x.C, 1, NP)
+            T = acts["tgru.ctx"]["T"]
+            gxs = [gx.reshape(N // T, T, x.C)]
+        elif kind == "gru_bi":
+            up = self._entry(w, out, gout, N, NP, grads)
+            x = acts["x"]
+            gxt = w.get("gx0", (x.C, x.L, NP))
+            self._bwd_fgru(w, N, NP, seq, up, acts["hout"], x, None, gxt, grads)
+            gxs = [self._unload(gxt, N, x.C, x.L, NP).transpose(1, 2)]
+        elif kind == "std":
+            conv = seq[0]
+            x = acts["x"]
+            dy, _, _ = self._entry(w, out, gout, N, NP, grads, relu=True)
+            self._bwd_first(w, N, NP, conv, x, dy, out.L, grads)
+            k, s_, pad = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+            gxt = w.get("gx0", (x.C, x.L, NP))       # (the full network never needs it: features carry no gradient)
+            self._gemm(w, N=N, NP=NP, P=x.L, M=x.C, out=gxt, out_L=x.L, W=conv.weight.data, ldw_m=k, ldw_c=x.C * k,
+                       segs=[make_seg(dy, out.C, out.L, pos_off=pad - kk, pos_div=s_, woff=kk) for kk in range(k)])
+            gxs = [self._unload(gxt, N, x.C, x.L, NP)]
+        elif kind == "dsc":
+            up = self._entry(w, out, gout, N, NP, grads)
+            x = acts["x"]
+            gxt = w.get("gx0", (x.C, x.L, NP))
+            self._bwd_dsc(w, N, NP, seq, acts["pw"], out, up, x, None, False, gxt, "dy:blk.pw", grads)
+            gxs = [self._unload(gxt, N, x.C, x.L, NP)]
+        else:
+            up = self._entry(w, out, gout, N, NP, grads, relu=(kind != "last_tr"))
+            x, x2 = acts["x"], acts["x2"]
+            gx1 = w.get("gx0", (x.C, x.L, NP))
+            gx2 = w.get("gx1", (x2.C, x2.L, NP)) if x2 is not None else None
+            self._bwd_tr(w, N, NP, seq[3], seq[0], acts["pw"], out.L, up, x, None, x2, acts["left"], gx1, gx2,
+                         "dy:blk.pw", grads)
+            gxs = [self._unload(gx1, N, x.C, x.L, NP)]
+            if x2 is not None:
+                gxs.append(self._unload(gx2, N, x2.C, x2.L, NP))
+        self._wg_finish(grads)
+        return grads, gxs
 
     def _gru(self, w, cur, gru, N, NP, training):
         """input projection (both directions, M = 6H) + recurrence; returns Act(hout [2H][L][NP])"""
@@ -526,13 +653,15 @@ class TRUNetEngine:
         state.steps += 1
         return self._pw(w, "tgru", [Act(state.h, Hh, Lg)], blk.conv[0], blk.conv[1], N, NP, False)
 
-    def forward(self, x, training, tgru_state=None, tgru_T=None):
+    def forward(self, x, training, tgru_state=None, tgru_T=None, record=False):
         net = self.net
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[2] == F_BINS
         x = x.contiguous()
         N, Cin = x.shape[0], x.shape[1]
         NP = ceil_to(N, FRAME_PAD)
-        w = self.ws(NP, x.device)
+        w = self.ws(NP, x.device, record)
+        if record:
+            w.gen += 1
         lib = L.lib()
         st = L.stream()
         acts = {}
@@ -574,7 +703,7 @@ class TRUNetEngine:
                                                   training)
         out = torch.empty((N, cur.C, cur.L), device=x.device, dtype=torch.float32)
         check(lib.trunet_from_frames_last(ptr(cur.t), ptr(out), N, cur.C, cur.L, NP, st), "from_frames_last")
-        return out, (acts, N, NP, w)
+        return out, (acts, N, NP, w, w.gen)
 
     # ------------------------------------------------------------------ backward
     def _bn_bwd(self, w, st, nparts, grads, part_name="partials"):
@@ -618,7 +747,6 @@ class TRUNetEngine:
     def _wgrad(self, w, *, N, NP, P, M, dz, dz_L, dz_bn, W, ldw_m, ldw_c, segs, grads, bias=None, a_pos_off=0,
                a_m_off=0, w_m_off=0, b_off=0, dz1=None):
         lib = L.lib()
-        numel = W.numel()
         a = WgradArgs()
         a.NP, a.N, a.P, a.p_begin = NP, N, P, 0
         a.M, a.a_L, a.a_pos_off, a.a_m_off = M, dz_L, a_pos_off, a_m_off
@@ -626,9 +754,10 @@ class TRUNetEngine:
         a.nseg = len(segs)
         for i, s in enumerate(segs):
             a.seg[i] = s
-        a.w_numel = numel
         a.a0 = ptr(dz)
         if dz_bn is not None:
+            if dz1 is None:
+                raise L.TrunetHipError("weight gradient behind a BatchNorm needs the raw conv output next to dy")
             a.a_mode = PRO_BNBWD
             a.a1, a.ac0, a.ac1, a.ac2 = ptr(dz1), ptr(dz_bn.ca), ptr(dz_bn.cb), ptr(dz_bn.cc)
         else:
@@ -646,166 +775,146 @@ class TRUNetEngine:
         else:
             check(lib.trunet_conv_wgrad(a, L.stream()), "conv_wgrad")
 
-    def _pw_bwd(self, w, *, N, NP, P, M, dz, dz1, dz_bn, W, bias, segs, outs, grads):
-        """Fused backward of a Conv1d(k=1)+BatchNorm layer (trunet_pw_bwd): weight/bias gradient and, per source
-        segment, the data gradient with its ReLU mask / skip accumulation / BatchNorm-backward statistics.
-        outs[i] = dict(out=tensor, src=Act or None (mask + statistics of that source), accum=bool)."""
+    @staticmethod
+    def _dz_seg(dy_, z_, bn_, C, Ln, **kw):
+        if bn_ is None:
+            return make_seg(dy_, C, Ln, mode=PRO_NONE, **kw)
+        return make_seg(dy_, C, Ln, mode=PRO_BNBWD, src1=z_, c0=bn_.ca, c1=bn_.cb, c2=bn_.cc, **kw)
+
+    def _pw_bwd(self, w, *, N, NP, P, M, dz, dz1, dz_bn, W, bias, segs, outs, grads, fused=True):
+        """Backward of a Conv1d(k=1)+BatchNorm layer: weight/bias gradient and, per source segment, the data gradient with
+        its ReLU mask / skip accumulation / BatchNorm-backward statistics.
+        outs[i] = dict(out=tensor, src=Act or None (mask, + statistics when src.bn), accum=bool).
+        One fused launch (trunet_pw_bwd) when the kernel supports the shape, else (TRUNET_ENOTSUP: e.g. tensors beyond
+        its 32-bit row offsets, thin layers) trunet_conv_wgrad + one trunet_conv_gemm per source."""
         lib = L.lib()
-        a = PwBwdArgs()
-        aw = a.w
-        numel = W.numel()
         K = sum(s.nchan for s in segs)
-        aw.NP, aw.N, aw.P, aw.p_begin = NP, N, P, 0
-        aw.M, aw.a_L, aw.a_pos_off, aw.a_m_off = M, P, 0, 0
-        aw.ldw_m, aw.ldw_c, aw.w_m_off = K, 1, 0
-        aw.nseg = len(segs)
-        aw.w_numel = numel
-        aw.a0, aw.a1 = ptr(dz), ptr(dz1)
-        aw.a_mode = PRO_BNBWD
-        aw.ac0, aw.ac1, aw.ac2 = ptr(dz_bn.ca), ptr(dz_bn.cb), ptr(dz_bn.cc)
-        aw.w_numel = self._wg_total                     # image stride of the shared buffer
-        aw.w_partials, aw.b_partials = self._wg_slot(W), self._wg_slot(bias)
-        aw.b_stride, aw.b_off = self._wg_total, 0
-        a.W = ptr(W.data)
-        nparts = lib.trunet_pw_bwd_nparts()
-        stat_parts = []
-        for i, (sg, o) in enumerate(zip(segs, outs)):
-            aw.seg[i] = sg
-            d = a.dg[i]
-            d.out = ptr(o["out"])
-            fl = DG_STORE
-            src = o.get("src")
-            if src is not None:
-                fl |= DG_MASK
-                d.zmask = ptr(src.t)
-                if src.bn is not None:
-                    fl |= DG_STATS
-                    part = w.flat("pwb_partials%d" % i, nparts * sg.nchan * 2)
-                    d.e2, d.partials = ptr(src.bn.mean), ptr(part)
-                    stat_parts.append((src.bn, "pwb_partials%d" % i))
+        if fused:
+            a = PwBwdArgs()
+            aw = a.w
+            aw.NP, aw.N, aw.P, aw.p_begin = NP, N, P, 0
+            aw.M, aw.a_L, aw.a_pos_off, aw.a_m_off = M, P, 0, 0
+            aw.ldw_m, aw.ldw_c, aw.w_m_off = K, 1, 0
+            aw.nseg = len(segs)
+            aw.a0, aw.a1 = ptr(dz), ptr(dz1)
+            aw.a_mode = PRO_BNBWD
+            aw.ac0, aw.ac1, aw.ac2 = ptr(dz_bn.ca), ptr(dz_bn.cb), ptr(dz_bn.cc)
+            aw.w_numel = self._wg_total                     # image stride of the shared buffer
+            aw.w_partials, aw.b_partials = self._wg_slot(W), self._wg_slot(bias)
+            aw.b_stride, aw.b_off = self._wg_total, 0
+            a.W = ptr(W.data)
+            nparts = lib.trunet_pw_bwd_nparts()
+            stat_parts = []
+            for i, (sg, o) in enumerate(zip(segs, outs)):
+                aw.seg[i] = sg
+                d = a.dg[i]
+                d.out = ptr(o["out"])
+                fl = DG_STORE
+                src = o.get("src")
+                if src is not None:
+                    fl |= DG_MASK
+                    d.zmask = ptr(src.t)
+                    if src.bn is not None:
+                        fl |= DG_STATS
+                        part = w.flat("pwb_partials%d" % i, nparts * sg.nchan * 2)
+                        d.e2, d.partials = ptr(src.bn.mean), ptr(part)
+                        stat_parts.append((src.bn, "pwb_partials%d" % i))
                 if o.get("accum"):
                     fl |= DG_ACCUM
-            d.flags = fl
-        if PROFILE is not None:
-            fl_ = 4.0 * N * M * sum(s.nchan * _seg_positions(s, 0, P) for s in segs)
-            name = "pw_bwd_small_kernel" if M <= 8 else \
-                "pw_bwd_kernel<%d, %s>" % (32 if M <= 64 else 64, "true" if K == 192 else "false")
-            with _Timed(name, fl_, "M%d K%s P%d" % (M, "+".join(str(s.nchan) for s in segs), P)):
-                check(lib.trunet_pw_bwd(a, L.stream()), "pw_bwd")
-        else:
-            check(lib.trunet_pw_bwd(a, L.stream()), "pw_bwd")
-        for bn, pname in stat_parts:
-            self._bn_bwd(w, bn, nparts, grads, part_name=pname)
-
-    def backward(self, ctx, gout):
-        """gout: (N, 8, 257) cotangent.  Returns {parameter tensor: gradient}."""
-        acts, N, NP, w = ctx
-        net = self.net
-        lib = L.lib()
-        st = L.stream()
-        grads = {}
-        self._wg_begin(w)
-        gout = gout.contiguous()
-        last = acts["dec5"]
-        dyt = w.get("dy:dec5", (last.C, last.L, NP))
-        check(lib.trunet_to_frames_last(ptr(gout), ptr(dyt), N, last.C, last.L, NP, st), "to_frames_last")
-
-        # current upstream gradient: (dy tensor, z tensor, BN state of that z or None)
-        dy, z, bn = dyt, last.t, None
-
-        def dz_segs(dy_, z_, bn_, C, Ln, **kw):
-            if bn_ is None:
-                return make_seg(dy_, C, Ln, mode=PRO_NONE, **kw)
-            return make_seg(dy_, C, Ln, mode=PRO_BNBWD, src1=z_, c0=bn_.ca, c1=bn_.cb, c2=bn_.cc, **kw)
-
-        # -------- decoder, last to first
-        for i in range(5, -1, -1):
-            seq = (net.decoder[i].LastTrCNN if i == 5 else net.decoder[i].TrCNN) if i > 0 else net.decoder[0].FirstTrCNN
-            ct, pw = seq[3], seq[0]
-            k, s_, pad = ct.kernel_size[0], ct.stride[0], ct.padding[0]
-            Ci, Co = ct.in_channels, ct.out_channels
-            a_pw = acts["dec%d.pw" % i]           # input of the transposed conv (raw pw output + BN)
-            Lo = acts["dec%d" % i].L
-            # transposed conv: weight/bias gradient
-            self._wgrad(w, N=N, NP=NP, P=Lo, M=Co, dz=dy, dz1=z, dz_L=Lo, dz_bn=bn, W=ct.weight, ldw_m=k,
-                        ldw_c=Co * k, segs=[a_pw.seg(pos_off=pad - kk, woff=kk, pos_div=s_) for kk in range(k)],
-                        grads=grads, bias=ct.bias)
-            # transposed conv: data gradient -> dy of the pw BN (+ stats)
-            dy_pw = w.get("dy:dec%d.pw" % i, (Ci, a_pw.L, NP))
-            segs = [dz_segs(dy, z, bn, Co, Lo, pos_mul=s_, pos_off=kk - pad, woff=kk) for kk in range(k)]
-            nparts = self._gemm(w, N=N, NP=NP, P=a_pw.L, M=Ci, out=dy_pw, out_L=a_pw.L, W=ct.weight.data,
-                                ldw_m=Co * k, ldw_c=k, segs=segs, zmask=a_pw.t, e0=a_pw.bn.scale, e1=a_pw.bn.shift,
-                                e2=a_pw.bn.mean, stats=Ci)
-            self._bn_bwd(w, a_pw.bn, nparts, grads)
-            dy, z, bn = dy_pw, a_pw.t, a_pw.bn
-            # pointwise conv over [x1 | skip]
-            Kin = pw.in_channels
-            if i > 0:
-                x1 = acts["dec%d" % (i - 1)]
-                skip = acts["enc%d" % (5 - i)]
-                left = (skip.L - x1.L) // 2
-                srcs = [x1.seg(pos_off=-left, woff=0), skip.seg(woff=x1.C)]
+                d.flags = fl
+            if PROFILE is not None:
+                fl_ = 4.0 * N * M * sum(s.nchan * _seg_positions(s, 0, P) for s in segs)
+                name = "pw_bwd_small_kernel" if M <= 8 else \
+                    "pw_bwd_kernel<%d, %s>" % (32 if M <= 64 else 64, "true" if K == 192 else "false")
+                with _Timed(name, fl_, "M%d K%s P%d" % (M, "+".join(str(s.nchan) for s in segs), P)):
+                    rc = lib.trunet_pw_bwd(a, L.stream())
             else:
-                x1 = acts.get("tgru", acts["fgru"])
-                skip, left = None, 0
-                srcs = [x1.seg()]
-            Lp = a_pw.L
-            p0, p1 = max(0, left), min(Lp, x1.L + left)
-            dy_x1 = w.get("dy:" + ("dec%d" % (i - 1) if i > 0 else ("tgru" if "tgru" in acts else "fgru")),
-                          (x1.C, x1.L, NP))
-            if p1 - p0 < x1.L:          # cropped positions of x1 (network.py:96-97 with a negative pad) get no gradient
-                q0, q1 = p0 - left, p1 - left
-                if q0 > 0:
-                    dy_x1[:, :q0].zero_()
-                if q1 < x1.L:
-                    dy_x1[:, q1:].zero_()
-            g_skip = w.get("dy:enc%d" % (5 - i), (skip.C, skip.L, NP)) if skip is not None else None
-            # decoder.5's 8-row layer stays on the three separate launches (1.64 ms): trunet_pw_bwd's vector-ALU variant
-            # for <= 8 rows is correct but measured slower at this size (2.7-3.3 ms: 256 partial images = 256 blocks
-            # leave too few waves in flight); TRUNET_FUSED_THIN=1 selects it
-            if FUSED_PWBWD and (pw.out_channels % 32 == 0 or (pw.out_channels <= 8 and FUSED_THIN)):
-                outs = [dict(out=dy_x1, src=x1)] + ([dict(out=g_skip)] if skip is not None else [])
-                self._pw_bwd(w, N=N, NP=NP, P=Lp, M=pw.out_channels, dz=dy, dz1=z, dz_bn=bn, W=pw.weight,
-                             bias=pw.bias, segs=srcs, outs=outs, grads=grads)
-                dy, z, bn = dy_x1, x1.t, x1.bn
-                continue
-            self._wgrad(w, N=N, NP=NP, P=Lp, M=pw.out_channels, dz=dy, dz1=z, dz_L=Lp, dz_bn=bn, W=pw.weight,
-                        ldw_m=Kin, ldw_c=1, segs=srcs, grads=grads, bias=pw.bias)
-            # data gradient, x1 part -> dy of x1's BN
-            nparts = self._gemm(w, N=N, NP=NP, P=p1 - p0, p_begin=p0, M=x1.C, out=dy_x1, out_L=x1.L,
-                                out_pos_off=-left, W=pw.weight.data, ldw_m=1, ldw_c=Kin,
-                                segs=[dz_segs(dy, z, bn, pw.out_channels, Lp)], zmask=x1.t, e0=x1.bn.scale,
-                                e1=x1.bn.shift, e2=x1.bn.mean, stats=x1.C)
-            self._bn_bwd(w, x1.bn, nparts, grads)
-            if skip is not None:   # raw (unmasked) gradient w.r.t. the skip activation
-                self._gemm(w, N=N, NP=NP, P=Lp, M=skip.C, out=g_skip, out_L=skip.L, W=pw.weight.data, ldw_m=1,
-                           ldw_c=Kin, w_m_off=x1.C, segs=[dz_segs(dy, z, bn, pw.out_channels, Lp)])
-            dy, z, bn = dy_x1, x1.t, x1.bn
+                rc = lib.trunet_pw_bwd(a, L.stream())
+            if rc == 0:
+                for bn, pname in stat_parts:
+                    self._bn_bwd(w, bn, nparts, grads, part_name=pname)
+                return
+            if rc != L.TRUNET_ENOTSUP:
+                check(rc, "pw_bwd")
+        # ---- separate launches
+        self._wgrad(w, N=N, NP=NP, P=P, M=M, dz=dz, dz1=dz1, dz_L=P, dz_bn=dz_bn, W=W, ldw_m=K, ldw_c=1, segs=segs,
+                    grads=grads, bias=bias)
+        for sg, o in zip(segs, outs):
+            src = o.get("src")
+            p0, p1 = max(0, -sg.pos_off), min(P, sg.L - sg.pos_off)
+            kw = {}
+            if src is not None:
+                if src.bn is not None:
+                    kw = dict(zmask=src.t, e0=src.bn.scale, e1=src.bn.shift, e2=src.bn.mean, stats=sg.nchan)
+                else:       # ReLU-only source (enc0): mask = z > 0
+                    one = w.get("ones%d" % sg.nchan, (sg.nchan,))
+                    zero = w.get("zeros%d" % sg.nchan, (sg.nchan,))
+                    one.fill_(1.0)
+                    zero.zero_()
+                    kw = dict(zmask=src.t, e0=one, e1=zero, e2=zero)
+            nparts = self._gemm(w, N=N, NP=NP, P=p1 - p0, p_begin=p0, M=sg.nchan, out=o["out"], out_L=sg.L,
+                                out_pos_off=sg.pos_off, W=W.data, ldw_m=1, ldw_c=K, w_m_off=sg.woff,
+                                segs=[self._dz_seg(dz, dz1, dz_bn, M, P)], epi=(EPI_ACCUM if o.get("accum") else 0), **kw)
+            if src is not None and src.bn is not None:
+                self._bn_bwd(w, src.bn, nparts, grads)
 
-        if "tgru.ctx" in acts:            # time-recurrent block between FGRU and the decoder
-            dy, z, bn = self._tgru_seq_bwd(w, acts, dy, bn, N, NP, grads)
+    # ---- block-level pieces of the backward schedule.  ``up`` = (dy, z, bn): the gradient at a layer's BatchNorm
+    # output with the ReLU mask applied, that layer's raw conv output and its BatchNorm state (bn None: dy is the
+    # gradient of the raw output itself).  Sources are Acts: with a BatchNorm state the data gradient is masked and its
+    # BatchNorm-backward sums are reduced ("bn"); ``*_relu`` marks a ReLU-only source (enc0); a raw source (block
+    # inputs, skip tensors) gets the plain gradient.
+    def _bwd_tr(self, w, N, NP, ct, pw, a_pw, Lo, up, x1, x1_mask, skip, left, dy_x1, g_skip, dy_pw_name, grads):
+        """FirstTrCNN / TrCNN / LastTrCNN (network.py:60-120): transposed conv, then the pointwise conv over
+        [x1 (padded / cropped by ``left``) | skip].  x1_mask: x1 itself when its BatchNorm+ReLU sits between x1 and this
+        block (full network), None for a raw block input."""
+        dy, z, bn = up
+        k, s_, pad = ct.kernel_size[0], ct.stride[0], ct.padding[0]
+        Ci, Co = ct.in_channels, ct.out_channels
+        # transposed conv: weight/bias gradient
+        self._wgrad(w, N=N, NP=NP, P=Lo, M=Co, dz=dy, dz1=z, dz_L=Lo, dz_bn=bn, W=ct.weight, ldw_m=k,
+                    ldw_c=Co * k, segs=[a_pw.seg(pos_off=pad - kk, woff=kk, pos_div=s_) for kk in range(k)],
+                    grads=grads, bias=ct.bias)
+        # transposed conv: data gradient -> dy of the pw BN (+ stats)
+        dy_pw = w.get(dy_pw_name, (Ci, a_pw.L, NP))
+        segs = [self._dz_seg(dy, z, bn, Co, Lo, pos_mul=s_, pos_off=kk - pad, woff=kk) for kk in range(k)]
+        nparts = self._gemm(w, N=N, NP=NP, P=a_pw.L, M=Ci, out=dy_pw, out_L=a_pw.L, W=ct.weight.data,
+                            ldw_m=Co * k, ldw_c=k, segs=segs, zmask=a_pw.t, e0=a_pw.bn.scale, e1=a_pw.bn.shift,
+                            e2=a_pw.bn.mean, stats=Ci)
+        self._bn_bwd(w, a_pw.bn, nparts, grads)
+        # pointwise conv over [x1 | skip]
+        Lp = a_pw.L
+        srcs = [x1.seg(pos_off=-left, woff=0)] + ([skip.seg(woff=x1.C)] if skip is not None else [])
+        p0, p1 = max(0, left), min(Lp, x1.L + left)
+        if p1 - p0 < x1.L:          # cropped positions of x1 (network.py:96-97 with a negative pad) get no gradient
+            q0, q1 = p0 - left, p1 - left
+            if q0 > 0:
+                dy_x1[:, :q0].zero_()
+            if q1 < x1.L:
+                dy_x1[:, q1:].zero_()
+        outs = [dict(out=dy_x1, src=x1_mask)] + ([dict(out=g_skip)] if skip is not None else [])
+        # decoder.5's 8-row layer stays on the three separate launches (1.64 ms): trunet_pw_bwd's vector-ALU variant
+        # for <= 8 rows is correct but measured slower at this size (2.7-3.3 ms: 256 partial images = 256 blocks
+        # leave too few waves in flight); TRUNET_FUSED_THIN=1 selects it
+        fused = FUSED_PWBWD and (pw.out_channels % 32 == 0 or (pw.out_channels <= 8 and FUSED_THIN))
+        self._pw_bwd(w, N=N, NP=NP, P=Lp, M=pw.out_channels, dz=dy_pw, dz1=a_pw.t, dz_bn=a_pw.bn, W=pw.weight,
+                     bias=pw.bias, segs=srcs, outs=outs, grads=grads, fused=fused)
 
-        # -------- FGRU.conv (pw over hout)
-        conv = net.FGRU.conv[0]
-        hout = acts["hout"]
-        gru = net.FGRU.GRU
+    def _bwd_fgru(self, w, N, NP, blk, up, hout, src, src_mask, dy_src, grads):
+        """GRUBlock(128, 64, 64, True) (network.py:45-58): pointwise conv over hout, the recurrence, the input
+        projection; dy_src receives the gradient of the block input ``src`` (masked + statistics when src_mask)."""
+        lib, st = L.lib(), L.stream()
+        dy, z, bn = up
+        conv, gru = blk.conv[0], blk.GRU
         Hh, Lg = gru.hidden_size, hout.L
         dhout = w.get("dhout", (2 * Hh, Lg, NP))
-        if FUSED_PWBWD:
-            self._pw_bwd(w, N=N, NP=NP, P=Lg, M=conv.out_channels, dz=dy, dz1=z, dz_bn=bn, W=conv.weight,
-                         bias=conv.bias, segs=[hout.seg()], outs=[dict(out=dhout)], grads=grads)
-        else:
-            self._wgrad(w, N=N, NP=NP, P=Lg, M=conv.out_channels, dz=dy, dz1=z, dz_L=Lg, dz_bn=bn, W=conv.weight,
-                        ldw_m=conv.in_channels, ldw_c=1, segs=[hout.seg()], grads=grads, bias=conv.bias)
-            self._gemm(w, N=N, NP=NP, P=Lg, M=2 * Hh, out=dhout, out_L=Lg, W=conv.weight.data, ldw_m=1,
-                       ldw_c=conv.in_channels, segs=[dz_segs(dy, z, bn, conv.out_channels, Lg)])
+        self._pw_bwd(w, N=N, NP=NP, P=Lg, M=conv.out_channels, dz=dy, dz1=z, dz_bn=bn, W=conv.weight,
+                     bias=conv.bias, segs=[hout.seg()], outs=[dict(out=dhout)], grads=grads, fused=FUSED_PWBWD)
         # -------- GRU recurrence backward
         dgi = w.get("dgi", (6 * Hh, Lg, NP))
         dghn = w.get("dghn", (2 * Hh, Lg, NP))
         gates = w.t["gates"]
         check(lib.trunet_gru_bwd(ptr(dhout), ptr(hout.t), ptr(gates), ptr(gru.weight_hh_l0.data),
                                  ptr(gru.weight_hh_l0_reverse.data), ptr(dgi), ptr(dghn), Hh, Lg, NP, N, st), "gru_bwd")
-        enc5 = acts["enc5"]
         for d, sfx in enumerate(("", "_reverse")):
             whh = getattr(gru, "weight_hh_l0" + sfx)
             bhh = getattr(gru, "bias_hh_l0" + sfx)
@@ -819,76 +928,102 @@ class TRUNetEngine:
                         W=whh, ldw_m=Hh, ldw_c=1, segs=[hseg], grads=grads, bias=bhh, b_off=2 * Hh)
             # input projection weights: all 3H = 192 rows of dgi for this direction in one launch
             self._wgrad(w, N=N, NP=NP, P=Lg, M=3 * Hh, dz=dgi, dz_L=Lg, dz_bn=None, a_m_off=d * 3 * Hh, W=wih_p,
-                        ldw_m=gru.input_size, ldw_c=1, segs=[enc5.seg()], grads=grads, bias=bih_p, b_off=0)
-        # data gradient of the projection -> dy of enc5's BN
+                        ldw_m=gru.input_size, ldw_c=1, segs=[src.seg()], grads=grads, bias=bih_p, b_off=0)
+        # data gradient of the projection -> gradient of the block input (dy of enc5's BN in the full network)
         wih = w.t["wih"]
-        dy5 = w.get("dy:enc5", (enc5.C, enc5.L, NP))
-        nparts = self._gemm(w, N=N, NP=NP, P=Lg, M=enc5.C, out=dy5, out_L=enc5.L, W=wih, ldw_m=1,
-                            ldw_c=gru.input_size, segs=[make_seg(dgi, 6 * Hh, Lg)], zmask=enc5.t,
-                            e0=enc5.bn.scale, e1=enc5.bn.shift, e2=enc5.bn.mean, stats=enc5.C)
-        self._bn_bwd(w, enc5.bn, nparts, grads)
-        dy, z, bn = dy5, enc5.t, enc5.bn
+        kw = {}
+        if src_mask is not None:
+            kw = dict(zmask=src.t, e0=src.bn.scale, e1=src.bn.shift, e2=src.bn.mean, stats=src.C)
+        nparts = self._gemm(w, N=N, NP=NP, P=Lg, M=src.C, out=dy_src, out_L=src.L, W=wih, ldw_m=1,
+                            ldw_c=gru.input_size, segs=[make_seg(dgi, 6 * Hh, Lg)], **kw)
+        if src_mask is not None:
+            self._bn_bwd(w, src.bn, nparts, grads)
 
-        # -------- encoder 5..1
-        for i in range(5, 0, -1):
-            seq = net.encoder[i].DepthwiseSeparableConv1d
-            pw, dwc = seq[0], seq[3]
-            a_pw = acts["enc%d.pw" % i]
-            a_dw = acts["enc%d" % i]
-            k, s_ = dwc.kernel_size[0], dwc.stride[0]
-            C = dwc.out_channels
-            dy_pw = w.get("dy:enc%d.pw" % i, (C, a_pw.L, NP))
-            nparts = lib.trunet_dwconv_bwd_nparts(a_pw.L)
-            part = w.flat("partials_dw", nparts * C * 2)
-            wpart = w.flat("dw_w_partials", nparts * C * k)
-            bpart = w.flat("dw_b_partials", nparts * C)
-            check(lib.trunet_dwconv_bwd(ptr(dy), ptr(z), ptr(bn.ca), ptr(bn.cb), ptr(bn.cc), ptr(a_pw.t),
-                                        ptr(a_pw.bn.scale), ptr(a_pw.bn.shift), ptr(a_pw.bn.mean),
-                                        ptr(dwc.weight.data), ptr(dy_pw), ptr(part), ptr(wpart), ptr(bpart), C, k, s_,
-                                        a_pw.L, a_dw.L, NP, N, st), "dwconv_bwd")
-            gw = torch.empty_like(dwc.weight)
-            gb = torch.empty_like(dwc.bias)
-            check(lib.trunet_reduce_partials(ptr(gw), ptr(wpart), nparts, C * k, 0, st), "reduce")
-            check(lib.trunet_reduce_partials(ptr(gb), ptr(bpart), nparts, C, 0, st), "reduce")
-            grads[dwc.weight], grads[dwc.bias] = gw, gb
-            self._bn_bwd(w, a_pw.bn, nparts, grads, part_name="partials_dw")
-            dy, z, bn = dy_pw, a_pw.t, a_pw.bn
-            prev = acts["enc%d" % (i - 1)]
-            Lp = a_pw.L
-            # data gradient -> dy of prev (accumulating the decoder's skip gradient already stored there)
-            dy_prev = w.get("dy:enc%d" % (i - 1), (prev.C, prev.L, NP))
-            has_skip = (i - 1) <= 4
-            if FUSED_PWBWD and has_skip:
-                self._pw_bwd(w, N=N, NP=NP, P=Lp, M=pw.out_channels, dz=dy, dz1=z, dz_bn=bn, W=pw.weight,
-                             bias=pw.bias, segs=[prev.seg()], outs=[dict(out=dy_prev, src=prev, accum=True)],
-                             grads=grads)
-                dy, z, bn = (dy_prev, prev.t, prev.bn) if prev.bn is not None else (dy_prev, None, None)
-                continue
-            self._wgrad(w, N=N, NP=NP, P=Lp, M=pw.out_channels, dz=dy, dz1=z, dz_L=Lp, dz_bn=bn, W=pw.weight,
-                        ldw_m=pw.in_channels, ldw_c=1, segs=[prev.seg()], grads=grads, bias=pw.bias)
-            if prev.bn is not None:
-                nparts = self._gemm(w, N=N, NP=NP, P=Lp, M=prev.C, out=dy_prev, out_L=prev.L, W=pw.weight.data,
-                                    ldw_m=1, ldw_c=pw.in_channels, segs=[dz_segs(dy, z, bn, pw.out_channels, Lp)],
-                                    epi=(EPI_ACCUM if has_skip else 0), zmask=prev.t, e0=prev.bn.scale,
-                                    e1=prev.bn.shift, e2=prev.bn.mean, stats=prev.C)
-                self._bn_bwd(w, prev.bn, nparts, grads)
-                dy, z, bn = dy_prev, prev.t, prev.bn
-            else:   # enc0: ReLU only (mask = a0 > 0), no BN
-                one = w.get("ones64", (prev.C,))
-                zero = w.get("zeros64", (prev.C,))
-                one.fill_(1.0)
-                zero.zero_()
-                self._gemm(w, N=N, NP=NP, P=Lp, M=prev.C, out=dy_prev, out_L=prev.L, W=pw.weight.data, ldw_m=1,
-                           ldw_c=pw.in_channels, segs=[dz_segs(dy, z, bn, pw.out_channels, Lp)], epi=EPI_ACCUM,
-                           zmask=prev.t, e0=one, e1=zero, e2=zero)
-                dy, z, bn = dy_prev, None, None
+    def _bwd_dsc(self, w, N, NP, seq, a_pw, a_dw, up, prev, prev_mask, accum, dy_prev, dy_pw_name, grads):
+        """DepthwiseSeparableConv1d (network.py:24-43): depthwise conv (fused dgrad + wgrad + BN-backward sums of the
+        pointwise BatchNorm), then the pointwise conv; dy_prev receives the gradient of the block input ``prev``
+        (added to the skip gradient already stored there when ``accum``)."""
+        lib, st = L.lib(), L.stream()
+        dy, z, bn = up
+        pw, dwc = seq[0], seq[3]
+        k, s_ = dwc.kernel_size[0], dwc.stride[0]
+        C = dwc.out_channels
+        dy_pw = w.get(dy_pw_name, (C, a_pw.L, NP))
+        nparts = lib.trunet_dwconv_bwd_nparts(a_pw.L)
+        part = w.flat("partials_dw", nparts * C * 2)
+        wpart = w.flat("dw_w_partials", nparts * C * k)
+        bpart = w.flat("dw_b_partials", nparts * C)
+        check(lib.trunet_dwconv_bwd(ptr(dy), ptr(z), ptr(bn.ca), ptr(bn.cb), ptr(bn.cc), ptr(a_pw.t),
+                                    ptr(a_pw.bn.scale), ptr(a_pw.bn.shift), ptr(a_pw.bn.mean),
+                                    ptr(dwc.weight.data), ptr(dy_pw), ptr(part), ptr(wpart), ptr(bpart), C, k, s_,
+                                    a_pw.L, a_dw.L, NP, N, st), "dwconv_bwd")
+        gw = torch.empty_like(dwc.weight)
+        gb = torch.empty_like(dwc.bias)
+        check(lib.trunet_reduce_partials(ptr(gw), ptr(wpart), nparts, C * k, 0, st), "reduce")
+        check(lib.trunet_reduce_partials(ptr(gb), ptr(bpart), nparts, C, 0, st), "reduce")
+        grads[dwc.weight], grads[dwc.bias] = gw, gb
+        self._bn_bwd(w, a_pw.bn, nparts, grads, part_name="partials_dw")
+        self._pw_bwd(w, N=N, NP=NP, P=a_pw.L, M=pw.out_channels, dz=dy_pw, dz1=a_pw.t, dz_bn=a_pw.bn, W=pw.weight,
+                     bias=pw.bias, segs=[prev.seg()], outs=[dict(out=dy_prev, src=prev_mask, accum=accum)],
+                     grads=grads, fused=FUSED_PWBWD)
 
-        # -------- first conv: weight/bias gradient (one segment per tap of the input)
-        c0 = net.encoder[0].StandardConv1d[0]
-        xa = acts["x"]
+    def _bwd_first(self, w, N, NP, c0, xa, dy, Lo, grads):
+        """StandardConv1d (network.py:9-21): weight/bias gradient, one segment per tap of the input"""
         k, s_, pad = c0.kernel_size[0], c0.stride[0], c0.padding[0]
         segs = [make_seg(xa.t, xa.C, xa.L, pos_mul=s_, pos_off=kk - pad, woff=kk) for kk in range(k)]
-        self._wgrad(w, N=N, NP=NP, P=128, M=c0.out_channels, dz=dy, dz_L=128, dz_bn=None, W=c0.weight,
+        self._wgrad(w, N=N, NP=NP, P=Lo, M=c0.out_channels, dz=dy, dz_L=Lo, dz_bn=None, W=c0.weight,
                     ldw_m=xa.C * k, ldw_c=k, segs=segs, grads=grads, bias=c0.bias)
+
+    def backward(self, ctx, gout):
+        """gout: (N, 8, 257) cotangent.  Returns {parameter tensor: gradient}."""
+        acts, N, NP, w, gen = ctx
+        self._check_gen(w, gen)
+        net = self.net
+        lib = L.lib()
+        st = L.stream()
+        grads = {}
+        self._wg_begin(w)
+        gout = gout.contiguous()
+        last = acts["dec5"]
+        dyt = w.get("dy:dec5", (last.C, last.L, NP))
+        check(lib.trunet_to_frames_last(ptr(gout), ptr(dyt), N, last.C, last.L, NP, st), "to_frames_last")
+
+        # current upstream gradient: (dy tensor, z tensor, BN state of that z or None)
+        up = (dyt, last.t, None)
+        # -------- decoder, last to first
+        for i in range(5, -1, -1):
+            seq = (net.decoder[i].LastTrCNN if i == 5 else net.decoder[i].TrCNN) if i > 0 else net.decoder[0].FirstTrCNN
+            if i > 0:
+                x1, x1n = acts["dec%d" % (i - 1)], "dec%d" % (i - 1)
+                skip = acts["enc%d" % (5 - i)]
+                left = (skip.L - x1.L) // 2
+                g_skip = w.get("dy:enc%d" % (5 - i), (skip.C, skip.L, NP))
+            else:
+                x1n = "tgru" if "tgru" in acts else "fgru"
+                x1, skip, left, g_skip = acts[x1n], None, 0, None
+            dy_x1 = w.get("dy:" + x1n, (x1.C, x1.L, NP))
+            self._bwd_tr(w, N, NP, seq[3], seq[0], acts["dec%d.pw" % i], acts["dec%d" % i].L, up, x1, x1, skip, left,
+                         dy_x1, g_skip, "dy:dec%d.pw" % i, grads)
+            up = (dy_x1, x1.t, x1.bn)
+
+        if "tgru.ctx" in acts:            # time-recurrent block between FGRU and the decoder
+            up = self._tgru_seq_bwd(w, acts, up[0], up[2], N, NP, grads)
+
+        # -------- FGRU
+        enc5 = acts["enc5"]
+        dy5 = w.get("dy:enc5", (enc5.C, enc5.L, NP))
+        self._bwd_fgru(w, N, NP, net.FGRU, up, acts["hout"], enc5, enc5, dy5, grads)
+        up = (dy5, enc5.t, enc5.bn)
+
+        # -------- encoder 5..1: the data gradient accumulates onto the decoder's skip gradient stored in dy:enc{i-1}
+        for i in range(5, 0, -1):
+            prev = acts["enc%d" % (i - 1)]
+            dy_prev = w.get("dy:enc%d" % (i - 1), (prev.C, prev.L, NP))
+            self._bwd_dsc(w, N, NP, net.encoder[i].DepthwiseSeparableConv1d, acts["enc%d.pw" % i], acts["enc%d" % i], up,
+                          prev, prev, True, dy_prev, "dy:enc%d.pw" % i, grads)
+            up = (dy_prev, prev.t, prev.bn)
+
+        # -------- first conv (its output is ReLU-only: up[0] is already masked)
+        self._bwd_first(w, N, NP, net.encoder[0].StandardConv1d[0], acts["x"], up[0], acts["enc0"].L, grads)
         self._wg_finish(grads)
         return grads

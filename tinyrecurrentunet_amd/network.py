@@ -23,23 +23,46 @@ def _pw_bn_relu(cin, cout):
     return [nn.Conv1d(cin, cout, kernel_size=1), nn.BatchNorm1d(cout), nn.ReLU(inplace=True)]
 
 
+class _BlockFn(torch.autograd.Function):
+    """One autograd node per stand-alone block: forward/backward are the same HIP launches the fused ``TRUNet``
+    schedule uses for that block (engine.block_forward / block_backward); gradients for parameters and inputs."""
+
+    @staticmethod
+    def forward(ctx, engine, run, training, nx, *tensors):
+        out, ectx = run(training)          # eval-mode forwards record nothing (their backward raises)
+        ctx.engine, ctx.ectx, ctx.nx, ctx.training = engine, ectx, nx, training
+        ctx.params = tensors[nx:]
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        if not ctx.training:
+            raise _lib.TrunetHipError("backward through a block in eval() mode is not supported (BatchNorm running "
+                                      "statistics); call .train()")
+        grads, gxs = ctx.engine.block_backward(ctx.ectx, gout)
+        return (None, None, None, None) + tuple(gxs) + tuple(grads.get(p) for p in ctx.params)
+
+
+def _run_block(mod, run, xs):
+    """run(record) -> (y, ctx).  With autograd recording: through _BlockFn (backward in training mode only, like TRUNet)."""
+    if torch.is_grad_enabled() and (any(p.requires_grad for p in mod.parameters()) or any(x.requires_grad for x in xs)):
+        return _BlockFn.apply(mod._engine, run, mod.training, len(xs), *xs, *mod.parameters())
+    return run(False)[0]
+
+
 class _Block(nn.Module):
-    """Stand-alone use of a block class (the reference's own forward signatures).  Forward only: gradients are
-    produced by the fused schedule behind ``TRUNet``."""
+    """Stand-alone use of a block class (the reference's own forward signatures and autograd behaviour)."""
     _kind = None
     _seq = None
 
     def _run(self, *xs):
         for x in xs:
             _need_gpu(x)
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and \
-                any(x.requires_grad for x in xs):
-            raise _lib.TrunetHipError("stand-alone blocks are forward-only; train through TRUNet")
         if getattr(self, "_engine", None) is None:
             object.__setattr__(self, "_engine", TRUNetEngine(self))
-        with torch.no_grad():
-            return self._engine.block_forward(self._kind, getattr(self, self._seq), [x.float() for x in xs],
-                                              self.training)
+        xf = [x.float() for x in xs]
+        return _run_block(self, lambda rec: self._engine.block_forward(self._kind, getattr(self, self._seq), xf,
+                                                                      self.training, record=rec), xs)
 
 
 class StandardConv1d(_Block):
@@ -85,8 +108,8 @@ class GRUBlock(nn.Module):
         _need_gpu(x)
         if getattr(self, "_engine", None) is None:
             object.__setattr__(self, "_engine", TRUNetEngine(self))
-        with torch.no_grad():
-            return self._engine.gru_block_forward(self, x.float(), self.training)
+        xf = x.float()
+        return _run_block(self, lambda rec: self._engine.gru_block_forward(self, xf, self.training, record=rec), [x])
 
 
 def _trcnn_body(in_channels, out_channels, kernel_size, stride, tail=True):
@@ -140,7 +163,7 @@ class _TRUNetFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, engine, training, tgru_T, *params):
-        out, ectx = engine.forward(x, training, tgru_T=tgru_T)
+        out, ectx = engine.forward(x, training, tgru_T=tgru_T, record=training)
         ctx.engine, ctx.ectx, ctx.params = engine, ectx, params
         ctx.training = training
         return out
