@@ -300,6 +300,15 @@ int trunet_stft_mag(const float* x, const float* y, const float* win, const floa
 /* PhaseAwareMask.forward (phm.py:31-45 + R5) on interleaved complex64: out = sigmoid(beta(angle m - angle e)) |m| */
 int trunet_phm_fwd(const float* mix_ri, const float* est_ri, float* out, int64_t n, float beta, void* stream);
 
+/* ---- input pipeline on the GPU ----
+ * DataAugment.__call__ + the clean/noise mix (dataset.py:116-126, :380) for a whole batch resident in HBM:
+ *   noise' = clamp(hp(clamp(lp(gain * noise), -1, 1)), -1, 1);   noisy = clean + noise'      (clean == NULL: noisy = noise')
+ * noise, clean, noisy, noise_out (optional copy of noise') are (B, L); params is (B, 11) = linear gain, then the low-pass
+ * and the high-pass biquad as b0, b1, b2, a1, a2 (normalised by a0; torchaudio.functional.lowpass_biquad /
+ * highpass_biquad -> lfilter(clamp=True), the calls of dataset.py:123-125).  noisy must not alias noise. */
+int trunet_augment_mix(const float* noise, const float* clean, const float* params, float* noisy, float* noise_out, int B,
+                       int L, void* stream);
+
 /* calibration: sustained fp32 MFMA rate at the device's operating clock (out: blocks*256 floats) */
 int trunet_debug_mfma_peak(float* out, int blocks, int iters, void* stream);
 

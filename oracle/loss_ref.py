@@ -27,7 +27,7 @@ def loss_fn(net, clean_B1L, noisy_B1L, ell_p_lambda=1.0, stft_lambda=1.0, stft_c
     den = fr.denoise_from_output(out, T, beta=beta, length=L)  # (B, L)
     clean = clean_B1L[:, 0]
     l1 = torch.abs(torch.nn.functional.l1_loss(den, clean))   # util.py:239-240
-    loss = l1 * ell_p_lambda
+    loss = l1                                                 # util.py:242: unscaled (ell_p_lambda is never used)
     info = {"l1": l1.detach()}
     if stft_lambda > 0:
         sc, mag = sl.mr_stft_loss(den, clean, **stft_config)

@@ -208,12 +208,29 @@ def gen_sched(ref):
     save("sched", lrs=np.array(lrs, dtype=np.float64))
 
 
+def gen_config():
+    """the values of config/tiny.json's sections that reach the hot-path modules as **kwargs (train.py:180-192): data
+    for the drop-in tests (constructor / loss_fn / loader keyword names and values), no code"""
+    import json
+    cfg = json.load(open(os.path.join(REF, "config", "tiny.json")))
+    out = {"network": cfg["network"], "loss_config": cfg["train"]["loss_config"],
+           "optimization": cfg["train"]["optimization"],
+           "trainset": {k: v for k, v in cfg["trainset"].items() if k != "root"}, "dist": cfg["dist"]}
+    with open(os.path.join(HERE, "tiny_config_sections.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("wrote tiny_config_sections.json")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if sys.argv[1:] == ["config"]:
+        gen_config()
+        sys.exit(0)
     ref = load_reference()
     if len(sys.argv) > 1:               # python tests/golden/make_golden.py block:gru_uni ...  (add single fixtures)
         gen_blocks(ref, only=[a.split(":", 1)[1] for a in sys.argv[1:] if a.startswith("block:")])
         sys.exit(0)
+    gen_config()
     gen_blocks(ref)
     gen_composition(ref)
     gen_stft_loss(ref)

@@ -123,6 +123,7 @@ def _declare(L):
         "trunet_stft_mag": [p, p, p, p, p, p, i, i, i, i, p],
         "trunet_stft_loss_bwd_gather": [p, p, p, p, p, p, p, i, i, i, i, i, p],
         "trunet_phm_fwd": [p, p, p, i64, f, p],
+        "trunet_augment_mix": [p, p, p, p, p, i, i, p],
         "trunet_debug_mfma_peak": [p, i, i, p],
     }
     for name, args in sig.items():
@@ -163,6 +164,24 @@ def make_seg(src0, nchan, L, pos_mul=1, pos_off=0, pos_div=1, woff=0, mode=PRO_N
     s.pos_mul, s.pos_off, s.pos_div = pos_mul, pos_off, pos_div
     s.woff, s.mode = woff, mode
     return s
+
+
+# ---- flat gradient registry: the TRU-Net backward leaves every parameter gradient as a view of ONE flat tensor (gaps
+# between parameters are zero); the gradient all-reduce and FusedAdamW look the buffer up here by storage address and
+# work on it in place instead of packing the ~100 gradients again.
+_FLAT = {}          # storage address -> (flat tensor, layout, total); the newest few are kept alive (1.2 MB each)
+
+
+def register_flat_grad(flat, layout, total):
+    """flat: 1-D fp32 tensor of ``total`` elements; layout: {id(parameter): element offset}"""
+    while len(_FLAT) >= 4:
+        del _FLAT[next(iter(_FLAT))]
+    _FLAT[flat.untyped_storage().data_ptr()] = (flat, layout, total)
+
+
+def flat_grad_of(grad):
+    """(flat tensor, layout, total) if ``grad`` is a view of a registered flat gradient"""
+    return _FLAT.get(grad.untyped_storage().data_ptr())
 
 
 _TW = {}

@@ -5,14 +5,17 @@ xGMI on one node).
 
 Differences in mechanism, not in results: the reference concatenates ~100 gradient tensors, all-reduces the
 copy and copies 100 slices back every step (:127-134), after 177 separate broadcasts at start (:105-108).
-Here gradients are packed by one multi-tensor op into a PERSISTENT flat fp32 buffer, one SUM all-reduce
-runs on it (1.19 MB: latency-bound on xGMI, so exactly one collective per step), and the averaged values
-are scattered back; parameters/buffers are broadcast as one flat tensor per dtype.  As in the reference,
+Here the TRU-Net backward already leaves every gradient as a view of ONE flat fp32 tensor (engine._wg_finish), so the
+SUM all-reduce runs on that tensor in place (1.19 MB: latency-bound on xGMI, so exactly one collective per step) and
+nothing is packed or scattered; gradients of any other module are packed by one multi-tensor op into a persistent
+flat buffer first.  Parameters/buffers are broadcast as one flat tensor per dtype.  As in the reference,
 parameters whose ``grad is None`` (the never-executed TGRU, R4) are skipped, BatchNorm is not synchronised
 and the loss all-reduce is only for logging."""
 import torch
 import torch.distributed as dist
 from torch.autograd import Variable
+
+from . import _lib
 
 
 def reduce_tensor(tensor, num_gpus):
@@ -53,11 +56,34 @@ class FlatGradAllReduce:
         self.module = module
         self.flat = None
         self.params = None
+        self.in_place = None      # True when the last reduce ran on the engine's flat gradient tensor itself
+
+    @staticmethod
+    def _engine_flat(params):
+        info = _lib.flat_grad_of(params[0].grad)
+        if info is None:
+            return None
+        flat, layout, _ = info
+        if len(layout) != len(params):
+            return None
+        base = flat.data_ptr()
+        for p in params:
+            o = layout.get(id(p))
+            if o is None or p.grad.data_ptr() != base + 4 * o:
+                return None
+        return flat
 
     def reduce(self):
         params = [p for p in self.module.parameters() if p.requires_grad and p.grad is not None]
         if not params:
             return
+        flat = self._engine_flat(params)
+        if flat is not None:               # every p.grad is a view of this tensor: reduce it where it lies
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            flat /= dist.get_world_size()
+            self.in_place = True
+            return
+        self.in_place = False
         key = tuple(id(p) for p in params)
         n = sum(p.numel() for p in params)
         if self.flat is None or self.params != key or self.flat.numel() != n:

@@ -138,11 +138,12 @@ class Workspace:
             t.zero_()
         return t
 
-    def flat(self, name, numel):
-        """Grow-only 1-D scratch buffer (stream order makes sharing between layers safe)."""
+    def flat(self, name, numel, zero=False):
+        """Grow-only 1-D scratch buffer (stream order makes sharing between layers safe); zero: zero-filled when it is
+        (re)allocated, not per call."""
         t = self.t.get(name)
         if t is None or t.numel() < numel:
-            t = torch.empty(max(numel, 1), device=self.dev, dtype=torch.float32)
+            t = (torch.zeros if zero else torch.empty)(max(numel, 1), device=self.dev, dtype=torch.float32)
             self.t[name] = t
         return t
 
@@ -709,17 +710,17 @@ class TRUNetEngine:
     def _bn_bwd(self, w, st, nparts, grads, part_name="partials"):
         m = st.module
         part = w.flat(part_name, nparts * st.C * 2)
-        dgamma = torch.empty(st.C, device=part.device, dtype=torch.float32)   # handed to autograd: never workspace
-        dbeta = torch.empty(st.C, device=part.device, dtype=torch.float32)
+        # dgamma / dbeta go straight into the parameters' slots of partial image 0 (the other images hold zeros there)
         check(L.lib().trunet_bn_finalize_bwd(ptr(part), nparts, st.C, st.count, ptr(m.weight.data), ptr(st.mean),
-                                             ptr(st.rstd), ptr(dgamma), ptr(dbeta), ptr(st.ca), ptr(st.cb),
-                                             ptr(st.cc), L.stream()), "bn_finalize_bwd")
-        grads[m.weight] = dgamma
-        grads[m.bias] = dbeta
+                                             ptr(st.rstd), self._wg_slot(m.weight), self._wg_slot(m.bias), ptr(st.ca),
+                                             ptr(st.cb), ptr(st.cc), L.stream()), "bn_finalize_bwd")
 
-    # ---- weight-gradient partial images: every conv / GRU weight and bias owns a slice of ONE buffer
-    # [nparts][total]; the launches write their per-workgroup partial images straight into it (image stride = total)
-    # and a single trunet_reduce_partials at the end of backward sums all of them (one launch instead of ~46).
+    # ---- gradient partial images: every parameter owns a slice of ONE buffer [nparts][total] (slices start at multiples
+    # of 64 elements).  The conv / GRU weight-gradient launches write their per-workgroup partial images straight into
+    # it (image stride = total); BatchNorm and depthwise gradients, which have their own small reductions, are written
+    # into image 0 only (the buffer is zero-filled when allocated and nothing else ever touches those slices or the
+    # gaps).  A single trunet_reduce_partials at the end of backward sums all images into ONE flat gradient tensor: every
+    # p.grad is a view of it, and the all-reduce / optimizer work on it in place (_lib.register_flat_grad).
     def _wg_begin(self, w):
         if getattr(self, "_wg_layout", None) is None:
             off, lay = 0, {}
@@ -727,7 +728,7 @@ class TRUNetEngine:
                 lay[p] = off
                 off += (p.numel() + 63) // 64 * 64
             self._wg_layout, self._wg_total = lay, off
-        self._wg_base = w.flat("wg_partials", L.lib().trunet_conv_wgrad_nparts() * self._wg_total)
+        self._wg_base = w.flat("wg_partials", L.lib().trunet_conv_wgrad_nparts() * self._wg_total, zero=True)
         self._wg_touched = {}
 
     def _wg_slot(self, p):
@@ -743,6 +744,8 @@ class TRUNetEngine:
         for p in self._wg_touched.values():
             o = self._wg_layout[p]
             grads[p] = flat[o:o + p.numel()].view_as(p)
+        if len(self._wg_touched) == len(self._wg_layout):
+            L.register_flat_grad(flat, {id(p): o for p, o in self._wg_layout.items()}, self._wg_total)
 
     def _wgrad(self, w, *, N, NP, P, M, dz, dz_L, dz_bn, W, ldw_m, ldw_c, segs, grads, bias=None, a_pos_off=0,
                a_m_off=0, w_m_off=0, b_off=0, dz1=None):
@@ -957,11 +960,8 @@ class TRUNetEngine:
                                     ptr(a_pw.bn.scale), ptr(a_pw.bn.shift), ptr(a_pw.bn.mean),
                                     ptr(dwc.weight.data), ptr(dy_pw), ptr(part), ptr(wpart), ptr(bpart), C, k, s_,
                                     a_pw.L, a_dw.L, NP, N, st), "dwconv_bwd")
-        gw = torch.empty_like(dwc.weight)
-        gb = torch.empty_like(dwc.bias)
-        check(lib.trunet_reduce_partials(ptr(gw), ptr(wpart), nparts, C * k, 0, st), "reduce")
-        check(lib.trunet_reduce_partials(ptr(gb), ptr(bpart), nparts, C, 0, st), "reduce")
-        grads[dwc.weight], grads[dwc.bias] = gw, gb
+        check(lib.trunet_reduce_partials(self._wg_slot(dwc.weight), ptr(wpart), nparts, C * k, 0, st), "reduce")
+        check(lib.trunet_reduce_partials(self._wg_slot(dwc.bias), ptr(bpart), nparts, C, 0, st), "reduce")
         self._bn_bwd(w, a_pw.bn, nparts, grads, part_name="partials_dw")
         self._pw_bwd(w, N=N, NP=NP, P=a_pw.L, M=pw.out_channels, dz=dy_pw, dz1=a_pw.t, dz_bn=a_pw.bn, W=pw.weight,
                      bias=pw.bias, segs=[prev.seg()], outs=[dict(out=dy_prev, src=prev_mask, accum=accum)],

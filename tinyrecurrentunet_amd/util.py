@@ -82,7 +82,7 @@ def loss_fn(net, X, ell_p, ell_p_lambda, stft_lambda, mrstftloss, pcen=None, **k
     out = net(feats, frames_per_seq=T) if getattr(net, "use_tgru", False) else net(feats)
     den, l1 = denoise(out, clean, T)
     l1 = torch.abs(l1)
-    loss = l1 * ell_p_lambda
+    loss = l1                  # util.py:239-242: the L1 term enters unscaled (ell_p / ell_p_lambda are accepted and unused)
     output_dic = {"l1": l1.detach()}
     if stft_lambda > 0:
         sc_loss, mag_loss = mrstftloss(den, clean)
