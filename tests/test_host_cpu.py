@@ -315,6 +315,11 @@ def test_entry_points_reject_null_and_bad_shapes():
     a.seg[0].mode = _lib.PRO_BNRELU
     assert lib.trunet_conv_gemm(a, None) == EINVAL                     # BatchNorm prologue without c0 / c1
     a.seg[0].mode = _lib.PRO_NONE
+    a.out_pos_off = 1
+    assert lib.trunet_conv_gemm(a, None) == EINVAL                     # output rows p + 1 run past out_L
+    a.out_pos_off, a.p_begin = -1, 0
+    assert lib.trunet_conv_gemm(a, None) == EINVAL                     # ... or start before row 0
+    a.out_pos_off = 0
     a.NP = 200
     assert lib.trunet_conv_gemm(a, None) == EINVAL                     # NP not a multiple of the frame tile
     w = _lib.WgradArgs()
@@ -323,6 +328,8 @@ def test_entry_points_reject_null_and_bad_shapes():
     w.a0, w.w_partials = 0x1000, 0x2000
     w.a_mode = _lib.PRO_BNBWD
     assert lib.trunet_conv_wgrad(w, None) == EINVAL                    # BNBWD on dz without a1 / coefficients
+    w.a_mode, w.a_pos_off = _lib.PRO_NONE, 2
+    assert lib.trunet_conv_wgrad(w, None) == EINVAL                    # dz rows p + 2 run past a_L
     pb = _lib.PwBwdArgs()
     assert lib.trunet_pw_bwd(pb, None) == EINVAL
     assert lib.trunet_relu_bwd_stats(None, None, None, None, None, None, 4, 4, 256, 200, None) == EINVAL

@@ -580,10 +580,15 @@ extern "C" int trunet_conv_gemm(const trunet_gemm_args* h, void* stream) {
     if ((h->epi & TRUNET_EPI_MASK) && (!h->zmask || !h->e0 || !h->e1)) return TRUNET_EINVAL;
     if ((h->epi & TRUNET_EPI_ACCUM) && !(h->epi & TRUNET_EPI_MASK)) return TRUNET_ENOTSUP;
     if ((h->epi & TRUNET_EPI_BIAS) && !h->bias) return TRUNET_EINVAL;
+    // extents: every output row p + out_pos_off must exist, statistics rows must cover the launch's channels
+    if (h->out_L <= 0 || h->p_begin < 0 || h->m_out_off < 0 || h->p_begin + h->out_pos_off < 0 ||
+        h->p_begin + h->P + h->out_pos_off > h->out_L)
+        return TRUNET_EINVAL;
+    if ((h->epi & TRUNET_EPI_STATS) && h->M_stat < h->M + h->m_out_off) return TRUNET_EINVAL;
     bool any_two = false, any_relu = false;
     for (int s = 0; s < h->nseg; ++s) {
         const trunet_seg& sg = h->seg[s];
-        if (!sg.src0 || sg.nchan <= 0 || sg.pos_div <= 0) return TRUNET_EINVAL;
+        if (!sg.src0 || sg.nchan <= 0 || sg.pos_div <= 0 || sg.L <= 0) return TRUNET_EINVAL;
         if (sg.mode == TRUNET_PRO_BNBWD && (!sg.src1 || !sg.c0 || !sg.c1 || !sg.c2)) return TRUNET_EINVAL;
         if (sg.mode == TRUNET_PRO_BNRELU && (!sg.c0 || !sg.c1)) return TRUNET_EINVAL;
         any_two = any_two || sg.mode == TRUNET_PRO_BNBWD;
@@ -977,12 +982,16 @@ extern "C" int trunet_conv_wgrad(const trunet_wgrad_args* h, void* stream) {
     if (!h || !h->a0 || !h->w_partials || h->nseg < 1 || h->nseg > TRUNET_MAX_SEG) return TRUNET_EINVAL;
     if (h->NP <= 0 || (h->NP % NT) != 0 || h->N > h->NP || h->P <= 0 || h->M <= 0 || h->M > 192) return TRUNET_EINVAL;
     if (h->a_mode == TRUNET_PRO_BNBWD && (!h->a1 || !h->ac0 || !h->ac1 || !h->ac2)) return TRUNET_EINVAL;
+    // extents: every dz row p + a_pos_off must exist; the partial images must hold the weight
+    if (h->a_L <= 0 || h->p_begin < 0 || h->a_m_off < 0 || h->p_begin + h->a_pos_off < 0 ||
+        h->p_begin + h->P + h->a_pos_off > h->a_L || h->w_numel <= 0)
+        return TRUNET_EINVAL;
     const bool two = h->a_mode == TRUNET_PRO_BNBWD;
     const int MA = (h->M + 31) & ~31;
     int tiles = 0, ntot = 0, allrows = 0, maxsrp = 0;
     for (int s = 0; s < h->nseg; ++s) {
         const trunet_seg& sg = h->seg[s];
-        if (!sg.src0 || sg.nchan <= 0 || sg.pos_div <= 0) return TRUNET_EINVAL;
+        if (!sg.src0 || sg.nchan <= 0 || sg.pos_div <= 0 || sg.L <= 0) return TRUNET_EINVAL;
         if (sg.mode == TRUNET_PRO_BNBWD) return TRUNET_ENOTSUP;
         if (sg.mode == TRUNET_PRO_BNRELU && (!sg.c0 || !sg.c1)) return TRUNET_EINVAL;
         const int srp = (sg.nchan + 31) & ~31;
