@@ -300,6 +300,19 @@ int trunet_stft_mag(const float* x, const float* y, const float* win, const floa
 /* PhaseAwareMask.forward (phm.py:31-45 + R5) on interleaved complex64: out = sigmoid(beta(angle m - angle e)) |m| */
 int trunet_phm_fwd(const float* mix_ri, const float* est_ri, float* out, int64_t n, float beta, void* stream);
 
+/* ---- eval-mode single-launch forward (rt.py:20-27 protocol, onnx.py:14-44 artefact role) ----
+ * The whole TRU-Net forward of network.py:153-171 (R1-R4, TGRU not executed) for N independent frames in ONE launch:
+ * x (N, Cin, 257) -> y (N, 8, 257), Cin in {3, 4}.  BatchNorm (eval: running statistics) is folded into the conv in front
+ * of it by the exporter; `blob` is the exported weight image (32-row tiles in MFMA fragment order) and h_offsets the 26
+ * element offsets of its sections (first conv | 5 encoder pw | 5 depthwise | GRU projection | W_hh, b_hh | FGRU conv |
+ * 6 decoder pw | 5 transposed convs | last transposed conv), as written by tinyrecurrentunet_amd/export.py.  Every
+ * workgroup takes one frame at a time through all layers in its own LDS; `scratch` holds the skip tensors of the frames
+ * in flight: trunet_stream_fwd_scratch_floats(trunet_stream_fwd_grid(N)) floats. */
+int trunet_stream_fwd_grid(int N);
+size_t trunet_stream_fwd_scratch_floats(int grid);
+int trunet_stream_fwd(const float* x, float* y, const float* blob, const int32_t* h_offsets, int n_offsets, float* scratch,
+                      int N, int Cin, void* stream);
+
 /* ---- input pipeline on the GPU ----
  * DataAugment.__call__ + the clean/noise mix (dataset.py:116-126, :380) for a whole batch resident in HBM:
  *   noise' = clamp(hp(clamp(lp(gain * noise), -1, 1)), -1, 1);   noisy = clean + noise'      (clean == NULL: noisy = noise')

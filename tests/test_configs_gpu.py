@@ -151,3 +151,48 @@ def test_cfg5_ablation_loss_vs_oracle(pcen, stft_lambda):
             continue
         errs.append(float((p.grad.double().cpu() - r).norm() / r.norm()))
     assert float(np.median(errs)) < 2e-2 and max(errs) < 2e-1, (np.median(errs), max(errs))
+
+
+@pytest.mark.parametrize("cin", [3, 4])
+def test_folded_single_launch_forward_matches_reference_golden(golden, cin, tmp_path):
+    """the BatchNorm-folded single-launch eval forward (export.py + stream_fwd.hip) against y_eval
+    of the reference composition (tests/golden/trunet_cin*.npz, 1e-4 relative as north_star asks), against the
+    layer-by-layer HIP forward, and through the exported artefact (save -> load with weights_only=True -> run)."""
+    from tinyrecurrentunet_amd import export
+    g = golden("trunet_cin%d" % cin)
+    _, net = _pair(cin, seed=0)
+    net.eval()
+    x = torch.tensor(g["x"]).cuda()
+    with torch.no_grad():
+        y = net(x)                                           # eval + no_grad: the folded path
+        assert net.__dict__.get("_folded_cache") is not None
+        assert _rel(y, torch.tensor(g["y_eval"])) < 1e-4
+        net.fold_eval = False
+        y_layers = net(x)
+        net.fold_eval = True
+        assert _rel(y, y_layers) < 1e-5
+        art = tmp_path / "trunet_folded.pt"
+        net.folded().save(str(art))
+        run = export.FoldedTRUNet.load(str(art), device=x.device)
+        assert torch.equal(run(x), y)
+        # a weight update invalidates the cached fold
+        net.decoder[5].LastTrCNN[3].bias.add_(1.0)
+        y2 = net(x)
+        assert float((y2 - y - 1.0).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("N", [1, 255, 1024, 2500])
+def test_folded_forward_vs_oracle_f64(N):
+    """ragged / multi-frame-per-workgroup counts (one workgroup takes frames n, n + grid, ...): 1e-4 vs the fp64 oracle"""
+    from oracle import network_ref as nr, weights as W
+    _, net = _pair(4, seed=6)
+    net.eval()
+    refd = W.fill_state_dict(nr.TRUNet(input_size=4), seed=6).double().eval()
+    x = torch.randn(N, 4, 257, generator=torch.Generator().manual_seed(N)) * 0.7
+    with torch.no_grad():
+        y = net(x.cuda())
+        yd = refd(x.double())
+    assert _rel(y, yd) < 1e-4, _rel(y, yd)
+    # per-frame relative error too: no frame may be off while the global maximum hides it
+    per = ((y.double().cpu() - yd).abs().amax((1, 2)) / yd.abs().amax((1, 2)))
+    assert float(per.max()) < 2e-4, float(per.max())

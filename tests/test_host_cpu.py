@@ -16,7 +16,7 @@ def test_c_abi_exports_every_declared_symbol():
     import ctypes
     from tinyrecurrentunet_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "trunet_hip.h")).read()
-    declared = set(re.findall(r"^\s*int\s+(trunet_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|size_t)\s+(trunet_\w+)\s*\(", hdr, flags=re.M))
     assert len(declared) >= 29
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:

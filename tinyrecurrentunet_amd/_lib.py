@@ -124,12 +124,16 @@ def _declare(L):
         "trunet_stft_loss_bwd_gather": [p, p, p, p, p, p, p, i, i, i, i, i, p],
         "trunet_phm_fwd": [p, p, p, i64, f, p],
         "trunet_augment_mix": [p, p, p, p, p, i, i, p],
+        "trunet_stream_fwd_grid": [i],
+        "trunet_stream_fwd_scratch_floats": [i],
+        "trunet_stream_fwd": [p, p, p, C.POINTER(C.c_int32), i, p, i, i, p],
         "trunet_debug_mfma_peak": [p, i, i, p],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = C.c_int
+    L.trunet_stream_fwd_scratch_floats.restype = C.c_size_t
     L._declared = sorted(sig)
 
 

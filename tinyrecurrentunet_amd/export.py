@@ -1,0 +1,154 @@
+"""Eval-mode export path (the role of ``/root/reference/onnx.py:14-44``: turn a checkpoint into
+a deployable inference artefact, and of ``rt.py:13-27``: load it and run the 1-frame forward).
+
+``fold(net)`` folds every BatchNorm (running statistics, eval semantics of network.py:31,39,51,65,72,...) into the conv
+in front of it and lays the weights out for the single-launch forward kernel ``trunet_stream_fwd`` (stream_fwd.hip):
+32-row tiles in MFMA fragment order (A fragments then 16 bias values per lane), per-tap matrices for the transposed
+convs.  The artefact is ONE flat fp32 tensor + 26 offsets; ``FoldedTRUNet.save`` / ``load`` store it with
+``torch.save`` and read it back with ``weights_only=True``.  ``FoldedTRUNet.forward(x)`` is the whole network in one
+kernel launch: (N, C_in, 257) -> (N, 8, 257), every frame independent (the reference's forward without TGRU, R4)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from ._lib import check, ptr
+
+
+def _bn_affine(bn):
+    scale = bn.weight.detach().double().cpu() / torch.sqrt(bn.running_var.detach().double().cpu() + bn.eps)
+    shift = bn.bias.detach().double().cpu() - bn.running_mean.detach().double().cpu() * scale
+    return scale, shift
+
+
+def _frag_tiles(Wm, bias):
+    """Wm (M, K) float64, bias (M,): per 32-row tile [K/8 quads of A fragments][4 quads of bias], each quad [64 lanes][4].
+    Lane l holds A[row l & 31][k = 2 kp + (l >> 5)] (v_mfma_f32_32x32x2_f32 A operand) and the bias of the 16 rows of
+    its accumulator registers (row = (r & 3) + 8 (r >> 2) + 4 (l >> 5))."""
+    M, K = Wm.shape
+    nrt = (M + 31) // 32
+    KP = (K + 15) // 16 * 8                      # k-pairs, multiple of 8 (the kernel's software pipeline)
+    Wp = np.zeros((nrt * 32, 2 * KP))
+    Wp[:M, :K] = Wm
+    bp = np.zeros(nrt * 32)
+    bp[:M] = bias
+    lane = np.arange(64)
+    out = []
+    for rt in range(nrt):
+        rows = rt * 32 + (lane & 31)                                          # (64,)
+        kp = np.arange(KP)
+        A = Wp[rows[None, :], 2 * kp[:, None] + (lane >> 5)[None, :]]        # (KP, 64)
+        A = A.reshape(KP // 4, 4, 64).transpose(0, 2, 1)                      # (quad, lane, 4)
+        r = np.arange(16)
+        brow = rt * 32 + (r & 3)[:, None] + 8 * (r >> 2)[:, None] + 4 * (lane >> 5)[None, :]
+        Bq = bp[brow].reshape(4, 4, 64).transpose(0, 2, 1)
+        out.append(np.concatenate([A.reshape(-1), Bq.reshape(-1)]))
+    return np.concatenate(out)
+
+
+def fold(net):
+    """TRUNet (network.py R1 layer sizes) -> (blob float32 ndarray, offsets int32[26], C_in)"""
+    sec, offs = [], []
+
+    def add(arr):
+        arr = np.asarray(arr, dtype=np.float64).reshape(-1)
+        pad = (-len(arr)) % 4
+        offs.append(sum(len(s) for s in sec))
+        sec.append(np.concatenate([arr, np.zeros(pad)]))
+
+    def t(x):
+        return x.detach().double().cpu().numpy()
+
+    c0 = net.encoder[0].StandardConv1d[0]
+    cin = c0.in_channels
+    add(np.concatenate([t(c0.weight).reshape(-1), t(c0.bias)]))                       # o_first
+    pws, dws = [], []
+    for i in range(1, 6):
+        seq = net.encoder[i].DepthwiseSeparableConv1d
+        sc, sh = _bn_affine(seq[1])
+        W = t(seq[0].weight)[:, :, 0] * sc.numpy()[:, None]
+        pws.append(_frag_tiles(W, t(seq[0].bias) * sc.numpy() + sh.numpy()))
+        sc, sh = _bn_affine(seq[4])
+        Wd = t(seq[3].weight)[:, 0, :] * sc.numpy()[:, None]
+        dws.append(np.concatenate([Wd.reshape(-1), t(seq[3].bias) * sc.numpy() + sh.numpy()]))
+    for a in pws:
+        add(a)                                                                         # o_pw[5]
+    for a in dws:
+        add(a)                                                                         # o_dw[5]
+    g = net.FGRU.GRU
+    Wih = np.concatenate([t(g.weight_ih_l0), t(g.weight_ih_l0_reverse)], 0)
+    bih = np.concatenate([t(g.bias_ih_l0), t(g.bias_ih_l0_reverse)], 0)
+    add(_frag_tiles(Wih, bih))                                                         # o_gi
+    add(np.concatenate([t(g.weight_hh_l0).reshape(-1), t(g.weight_hh_l0_reverse).reshape(-1), t(g.bias_hh_l0),
+                        t(g.bias_hh_l0_reverse)]))                                     # o_whh
+    sc, sh = _bn_affine(net.FGRU.conv[1])
+    fc = net.FGRU.conv[0]
+    add(_frag_tiles(t(fc.weight)[:, :, 0] * sc.numpy()[:, None], t(fc.bias) * sc.numpy() + sh.numpy()))   # o_fg
+    dpw, cts, last = [], [], None
+    for i in range(6):
+        seq = net.decoder[i].FirstTrCNN if i == 0 else (net.decoder[i].TrCNN if i < 5 else net.decoder[i].LastTrCNN)
+        sc, sh = _bn_affine(seq[1])
+        dpw.append(_frag_tiles(t(seq[0].weight)[:, :, 0] * sc.numpy()[:, None], t(seq[0].bias) * sc.numpy() + sh.numpy()))
+        ct = seq[3]
+        if i < 5:
+            sc, sh = _bn_affine(seq[4])
+            Wt = t(ct.weight) * sc.numpy()[None, :, None]                              # (Ci, Co, k)
+            A = np.concatenate([Wt[:, :, k].T for k in range(Wt.shape[2])], 1)         # (Co, k*Ci): tap-major K axis
+            cts.append(_frag_tiles(A, t(ct.bias) * sc.numpy() + sh.numpy()))
+        else:
+            last = np.concatenate([t(ct.weight).reshape(-1), t(ct.bias)])              # linear output layer
+    for a in dpw:
+        add(a)                                                                         # o_dpw[6]
+    for a in cts:
+        add(a)                                                                         # o_ct[5]
+    add(last)                                                                          # o_last
+    assert len(offs) == 26
+    return np.concatenate(sec).astype(np.float32), np.array(offs, dtype=np.int32), cin
+
+
+class FoldedTRUNet:
+    """The exported inference artefact and its runner (one kernel launch per forward)."""
+
+    def __init__(self, blob, offsets, cin, device=None):
+        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.blob = torch.as_tensor(blob, dtype=torch.float32).to(dev).contiguous()
+        self.offsets = np.ascontiguousarray(np.asarray(offsets, dtype=np.int32))
+        self._offs = (C.c_int32 * len(self.offsets))(*[int(v) for v in self.offsets])
+        self.cin = int(cin)
+        self._scratch = None
+
+    @classmethod
+    def from_module(cls, net, device=None):
+        blob, offs, cin = fold(net)
+        dev = device if device is not None else next(net.parameters()).device
+        return cls(blob, offs, cin, dev)
+
+    def save(self, path):
+        torch.save({"format": "trunet-folded-v1", "blob": self.blob.cpu(), "offsets": torch.tensor(self.offsets),
+                    "cin": self.cin}, path)
+
+    @classmethod
+    def load(cls, path, device=None):
+        d = torch.load(path, map_location="cpu", weights_only=True)
+        if d.get("format") != "trunet-folded-v1":
+            raise L.TrunetHipError("%s is not a folded TRU-Net artefact" % path)
+        return cls(d["blob"], d["offsets"].numpy(), int(d["cin"]), device)
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise L.TrunetHipError("tinyrecurrentunet_amd runs on MI355X only: got a %s tensor" % x.device)
+        x = x.contiguous().float()
+        if x.dim() != 3 or x.shape[1] != self.cin or x.shape[2] != 257:
+            raise ValueError("expected (N, %d, 257) features, got %s" % (self.cin, tuple(x.shape)))
+        N = x.shape[0]
+        lib = L.lib()
+        need = lib.trunet_stream_fwd_scratch_floats(lib.trunet_stream_fwd_grid(N))
+        if self._scratch is None or self._scratch.numel() < need or self._scratch.device != x.device:
+            self._scratch = torch.empty(need, device=x.device, dtype=torch.float32)
+        y = torch.empty((N, 8, 257), device=x.device, dtype=torch.float32)
+        check(lib.trunet_stream_fwd(ptr(x), ptr(y), ptr(self.blob), self._offs, len(self.offsets), ptr(self._scratch), N,
+                                    self.cin, L.stream()), "stream_fwd")
+        return y
+
+    __call__ = forward

@@ -240,8 +240,29 @@ class TRUNet(nn.Module):
         params = self._active_params()
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             return _TRUNetFn.apply(x, self._engine, self.training, T, *params)
+        if not self.training and T is None and self.fold_eval and 0 < x.shape[0] <= self.fold_max_frames:
+            # eval, no autograd: BatchNorm folded into the convs, the whole forward in ONE launch (export.py,
+            # stream_fwd.hip) -- the streaming / rt.py-protocol path
+            return self.folded()(x)
         out, _ = self._engine.forward(x, self.training, tgru_T=T)
         return out
+
+    # eval-mode single-launch forward: on by default for batches up to fold_max_frames frames (beyond that the
+    # layer-by-layer kernels, which share one weight load over all frames, are faster)
+    fold_eval = True
+    fold_max_frames = 8192
+
+    def folded(self):
+        """The exported inference artefact of the current weights (export.FoldedTRUNet), rebuilt when a parameter or
+        buffer has been modified since (tensor version counters)."""
+        from .export import FoldedTRUNet
+        ts = [t for n, t in self.state_dict(keep_vars=True).items() if not n.startswith("TGRU.")]
+        key = (tuple(t._version for t in ts), tuple(t.data_ptr() for t in ts[:2]), str(ts[0].device))
+        cached = self.__dict__.get("_folded_cache")
+        if cached is None or cached[0] != key:
+            cached = (key, FoldedTRUNet.from_module(self))
+            object.__setattr__(self, "_folded_cache", cached)
+        return cached[1]
 
 
 class TRUNetStreamState:
