@@ -146,12 +146,59 @@ def streaming(args, dev):
                 y = fwd(x)
         torch.cuda.synchronize()
     dt = (time.time() - t0) / args.steps
+    # roofline of the forward kernel: HIP events on the launch stream around direct (un-graphed) calls
+    roof = None
+    if not args.tgru:
+        with torch.no_grad():
+            evs = []
+            for _ in range(20):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                fwd(x)
+                b.record()
+                evs.append((a, b))
+            torch.cuda.synchronize()
+        kms = pctl([a.elapsed_time(b) for a, b in evs], 0.5)
+        flops = streams * (FLOPS_PER_FRAME_STEP / 3.0)            # forward: 31,363,072 flop per frame
+        ach = flops / (kms * 1e-3) / 1e12
+        folded = net.__dict__.get("_folded_cache") is not None
+        roof = {"bound": "mfma", "kernel": "stream_fwd_kernel" if folded else "layer-by-layer launches",
+                "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4),
+                "traffic": None, "avg_launch_ms": round(kms, 4),
+                "algorithmic_bytes_per_launch": streams * 12336,   # features in + output out per frame
+                "note": "per-frame independent eval forward, one workgroup per frame: bound by the fp32 MFMA rate "
+                        "(31.4 Mflop vs 12.3 KB per frame)"}
+    cpu = None
+    if not args.no_cpu_baseline and not args.tgru:
+        from oracle import network_ref as nr
+        cores = usable_cores()
+        torch.set_num_threads(cores)
+        torch.manual_seed(0)
+        ref = nr.TRUNet(input_size=4).eval()
+        xc = torch.randn(streams, 4, 257)
+        ts = []
+        with torch.no_grad():
+            for it in range(12):
+                t1 = time.time()
+                ref(xc)
+                ts.append(time.time() - t1)
+                if it >= 3 and sum(ts) > 30:
+                    break
+        ts = ts[1:]
+        cdt = pctl(ts, 0.5)
+        cpu = {"value": round(streams * 0.008 / cdt, 2), "unit": "x real time", "cores": cores, "kind": "port",
+               "frames_per_s": round(streams / cdt, 1), "timed_steps": len(ts),
+               "sample": "same workload: eval forward of randn(1024,4,257), median of %d calls after 1 warm-up, torch %s "
+                         "CPU" % (len(ts), torch.__version__)}
     out = {"metric": "streaming forward real-time factor (1024 streams x 1 frame)", "value": round(streams * 0.008 / dt, 1),
            "unit": "x real time", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True, "dtype": "f32", "data": "synthetic",
-           "frames_per_s": round(streams / dt, 1), "hip_graph": graphed,
+           "frames_per_s": round(streams / dt, 1), "hip_graph": graphed, "vs_baseline": None,
            "config": {"workload": "config/tiny.json TRU-Net eval forward%s, randn(1024,4,257) per step (rt.py protocol)" % (
-               " + stateful TGRU step (use_tgru streaming)" if args.tgru else "")}}
+               " + stateful TGRU step (use_tgru streaming)" if args.tgru else "")},
+           "roofline": roof, "cpu_baseline": cpu}
+    if cpu:
+        out["gpu_over_cpu"] = round(out["value"] / cpu["value"], 1)
     print(json.dumps(out), flush=True)
 
 

@@ -1,0 +1,46 @@
+"""Diagnostic: where one frame's cycles go inside stream_fwd_kernel (workgroup 0, first frame), from s_memtime stamps of a
+-DSF_STAMPS build (scripts/dbg/libsf_stamps.so, built by `bash scripts/build_dbg.sh`).  Prints cycles per phase."""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tinyrecurrentunet_amd import export, network as hn  # noqa: E402
+
+lib = C.CDLL(os.path.join(ROOT, "scripts", "dbg", os.environ.get("SF_LIB", "libsf_stamps.so")))
+lib.trunet_stream_fwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.c_int,
+                                  C.c_int, C.c_void_p]
+lib.trunet_stream_fwd_scratch_floats.restype = C.c_size_t
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+torch.manual_seed(0)
+net = hn.TRUNet(input_size=4).cuda().eval()
+f = export.FoldedTRUNet.from_module(net)
+x = torch.randn(N, 4, 257, device="cuda")
+y = torch.empty(N, 8, 257, device="cuda")
+grid = lib.trunet_stream_fwd_grid(N)
+nf = lib.trunet_stream_fwd_scratch_floats(grid)
+scratch = torch.zeros(nf, device="cuda")
+st = torch.cuda.current_stream().cuda_stream
+for _ in range(3):
+    assert lib.trunet_stream_fwd(x.data_ptr(), y.data_ptr(), f.blob.data_ptr(), f._offs, 26, scratch.data_ptr(), N, 4, st) == 0
+torch.cuda.synchronize()
+t0 = time.time()
+for _ in range(20):
+    lib.trunet_stream_fwd(x.data_ptr(), y.data_ptr(), f.blob.data_ptr(), f._offs, 26, scratch.data_ptr(), N, 4, st)
+torch.cuda.synchronize()
+dt = (time.time() - t0) / 20
+s = scratch[grid * 45056:].view(torch.int64)[:32].cpu().numpy().astype(np.int64)
+names = {0: "x+first conv", 1: "enc1", 2: "enc2-5 + GRU proj", 7: "W_hh load", 23: "GRU recurrence", 26: "guards",
+         8: "fgru pw + dec0", 9: "dec1-4", 13: "dec5"}
+order = [0, 1, 2, 7, 23, 26, 8, 9, 13, 14]
+tot = s[14] - s[0]
+print("N=%d grid=%d: %.3f ms per launch; frame 0 of workgroup 0: %d cycles" % (N, grid, dt * 1e3, tot))
+for a, b in zip(order[:-1], order[1:]):
+    print("  %-20s %8d  %5.1f %%" % (names[a], s[b] - s[a], 100.0 * (s[b] - s[a]) / tot))
+print("  enc3 (it=1, 2 column tiles = 128 MFMAs/wave): wait for own fragments %d  request next %d  pw %d  guards+dw+syncs %d" % (
+    s[28] - s[27], s[29] - s[28], s[30] - s[29], s[31] - s[30]))

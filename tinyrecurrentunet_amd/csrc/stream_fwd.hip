@@ -23,7 +23,10 @@
 namespace {
 
 constexpr int SF_T = 256;
-constexpr int SF_R0 = 0, SF_R1A = 18432, SF_R1B = 18432 + 9216, SF_R2 = 36864, SF_ARENA = 40448;   // floats
+constexpr int SF_R0 = 0, SF_R1A = 18432, SF_R1B = 18432 + 9216, SF_R2 = 36864, SF_ARENA = 40960;   // floats (160 KiB)
+// small fixed buffers behind the three activation regions: features of the frame, first-conv weights (resident for the
+// whole kernel), depthwise / last-layer weights of the current block, GRU state
+constexpr int SF_XB = SF_R2, SF_W0 = SF_R2 + 1088, SF_DWB = SF_R2 + 2432, SF_GRU = SF_R2 + 3200;
 constexpr int SF_SKIP = 8192 + 16384 + 8192 + 8192 + 4096;       // enc0..enc4 per workgroup (floats)
 
 __host__ __device__ constexpr int sf_ls(int L) { return (L + 8 + 15) / 16 * 16; }
@@ -51,36 +54,47 @@ __device__ __forceinline__ void sf_load(float* af, const float* tile, int lane) 
     const f32x4* p = (const f32x4*)tile + lane;
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
+#if defined(SF_ABL) && (SF_ABL & 8)      // diagnostic: no fragment loads at all (timing only)
+        const f32x4 t = {1.f + i, 2.f, 3.f, (float)lane};
+        (void)p;
+#else
         const f32x4 t = p[i * 64];
+#endif
         af[4 * i + 0] = t[0]; af[4 * i + 1] = t[1]; af[4 * i + 2] = t[2]; af[4 * i + 3] = t[3];
     }
 }
 
 // acc += A(af[0..KP)) * B, B[k = 2 kk + h][j = c] = S[kk * rs2] (S is the lane's base: row h, column of this lane).
-// Software-pipelined by hand: the B values of the next 8 k-pairs are requested before the MFMAs of the current 8.
+// One wave per SIMD must hide the LDS latency of its own B operand: the read for k-pair kk + LA is issued right before
+// the MFMA of k-pair kk, and the order is pinned (hipcc otherwise sinks every ds_read directly in front of the MFMA that
+// consumes it and the matrix pipe idles ~75 cycles per pair of MFMAs: measured 63 % -> see DESIGN.md).
 template <int KP>
 __device__ __forceinline__ void sf_mm(f32x16& acc, const float* af, const float* S, int rs2) {
-    static_assert(KP % 8 == 0, "k-pairs in blocks of 8");
-    float b0[8], b1[8];
+    constexpr int LA = 6;
+    float b[KP];
+#if defined(SF_ABL) && (SF_ABL & 1)      // diagnostic: no LDS reads for the B operand (wrong results, timing only)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) b0[j] = S[j * rs2];
+    for (int kk = 0; kk < KP; ++kk) b[kk] = af[kk] + (float)rs2;
+#define SF_ABL_NOB 1
+#else
+#define SF_ABL_NOB 0
+#endif
 #pragma unroll
-    for (int k0 = 0; k0 < KP; k0 += 16) {
-        if (k0 + 8 < KP) {
+    for (int kk = 0; kk < LA && kk < KP && !SF_ABL_NOB; ++kk) b[kk] = S[kk * rs2];
+#if defined(SF_ABL) && (SF_ABL & 2)      // diagnostic: every unrolled MFMA block runs twice (second pass from the I-cache)
+    for (int rep_ = 0; rep_ < 2; ++rep_) {
+        asm volatile("" ::: "memory");
+#endif
 #pragma unroll
-            for (int j = 0; j < 8; ++j) b1[j] = S[(k0 + 8 + j) * rs2];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[k0 + j], b0[j], acc, 0, 0, 0);
-        if (k0 + 8 < KP) {
-            if (k0 + 16 < KP) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) b0[j] = S[(k0 + 16 + j) * rs2];
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[k0 + 8 + j], b1[j], acc, 0, 0, 0);
-        }
+    for (int kk = 0; kk < KP; ++kk) {
+        if (kk + LA < KP && !SF_ABL_NOB) b[kk + LA] = S[(kk + LA) * rs2];
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], b[kk], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
+#if defined(SF_ABL) && (SF_ABL & 2)
+    }
+#endif
 }
 
 // zero the guard columns [-4, 0) and [L, L + 4) of a [rows][ls] buffer
@@ -102,12 +116,7 @@ __device__ __forceinline__ void sf_pw(const float* af, float* lds, int src1, int
     const int ct0 = NRT == 4 ? 0 : (NRT == 2 ? (wave >> 1) : wave);
     const int cts = NRT == 4 ? 1 : (NRT == 2 ? 2 : 4);
     const int nct = (P + 31) >> 5;
-    for (int ct = ct0; ct < nct; ct += cts) {
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        sf_mm<KP1>(acc, af, lds + src1 + h * ls1 + 4 + ct * 32 + c + coff1, 2 * ls1);
-        if constexpr (KP2 > 0) sf_mm<KP2>(acc, af + KP1, lds + src2 + h * ls2 + 4 + ct * 32 + c, 2 * ls2);
+    auto store = [&](const f32x16& acc, int ct) __attribute__((always_inline)) {
         const int col = ct * 32 + c;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -116,6 +125,15 @@ __device__ __forceinline__ void sf_pw(const float* af, float* lds, int src1, int
             if (relu) v = fmaxf(v, 0.f);
             if (col < P && row < M) lds[dst + (row0 + row) * lsd + 4 + col] = v;
         }
+    };
+    int ct = ct0;
+    for (; ct < nct; ct += cts) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        sf_mm<KP1>(acc, af, lds + src1 + h * ls1 + 4 + ct * 32 + c + coff1, 2 * ls1);
+        if constexpr (KP2 > 0) sf_mm<KP2>(acc, af + KP1, lds + src2 + h * ls2 + 4 + ct * 32 + c, 2 * ls2);
+        store(acc, ct);
     }
 }
 
@@ -156,14 +174,35 @@ __device__ __forceinline__ void sf_convT(const float* af, float* lds, int src, i
     }
 }
 
-// depthwise conv (k, stride s, padding k/2) + folded BatchNorm + ReLU; weights staged in LDS at `wl` ([C][k] then [C])
-__device__ __forceinline__ void sf_dw(float* lds, int src, int lsi, int dst, int lsd, int wl, int C, int K, int S, int Lout) {
-    for (int o = sf_tid(); o < C * Lout; o += SF_T) {
-        const int ch = o / Lout, lo = o - ch * Lout;
-        float v = lds[wl + C * K + ch];
-        const float* in = lds + src + ch * lsi + 4 + lo * S - K / 2;
-        for (int k = 0; k < K; ++k) v = fmaf(lds[wl + ch * K + k], in[k], v);
-        lds[dst + ch * lsd + 4 + lo] = fmaxf(v, 0.f);
+// depthwise conv (k = K, stride S, padding K/2) + folded BatchNorm + ReLU; weights staged in LDS at `wl` ([C][K] then [C]).
+// A lane produces 4 consecutive outputs of one channel row from the 16-byte quads that cover its input window
+// (conflict-free: consecutive lanes read consecutive quads of a row).  Lout is a multiple of 4.
+template <int K, int S>
+__device__ __forceinline__ void sf_dw(float* lds, int src, int lsi, int dst, int lsd, int wl, int C, int Lout) {
+    constexpr int NQ = (3 * S + K - 1 + K / 2 + 3) / 4 + 1;      // quads from 4 (j S - 1) on: covers [4 j S - K/2, 4 j S + 3 S + K/2]
+    const int Q = Lout >> 2;
+    for (int o = sf_tid(); o < C * Q; o += SF_T) {
+        const int ch = o / Q, j = o - ch * Q;
+        float w[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) w[k] = lds[wl + ch * K + k];
+        const float b = lds[wl + C * K + ch];
+        float in[4 * NQ];
+        const float* ip = lds + src + ch * lsi + 4 + 4 * j * S - 4;        // 16-byte aligned
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const f32x4 t = *(const f32x4*)(ip + 4 * q);
+            in[4 * q] = t[0]; in[4 * q + 1] = t[1]; in[4 * q + 2] = t[2]; in[4 * q + 3] = t[3];
+        }
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = b;
+#pragma unroll
+            for (int k = 0; k < K; ++k) v = fmaf(w[k], in[4 + e * S + k - K / 2], v);     // column 4 j S + e S + k - K/2
+            r[e] = fmaxf(v, 0.f);
+        }
+        *(f32x4*)(lds + dst + ch * lsd + 4 + 4 * j) = r;
     }
 }
 
@@ -171,19 +210,41 @@ __device__ __forceinline__ void sf_stage(float* lds, int at, const float* g, int
     for (int i = sf_tid(); i < n; i += SF_T) lds[at + i] = g[i];
 }
 
-// [C][L] dense (global scratch) <-> LDS buffer rows
-__device__ __forceinline__ void sf_save(const float* lds, int buf, int ls, float* g, int C, int L) {
-    for (int i = sf_tid(); i < C * L; i += SF_T) {
-        const int ch = i / L, p = i - ch * L;
-        g[i] = lds[buf + ch * ls + 4 + p];
+// [C][L] dense (global scratch) <-> LDS buffer rows, 16 bytes per access; L = 4 << lq (rows start 16-byte aligned)
+__device__ __forceinline__ void sf_save(const float* lds, int buf, int ls, float* g, int C, int lq) {
+    for (int i = sf_tid(); i < (C << lq); i += SF_T) {
+        const int ch = i >> lq, q = i - (ch << lq);
+        ((f32x4*)g)[i] = *(const f32x4*)(lds + buf + ch * ls + 4 + 4 * q);
     }
 }
-__device__ __forceinline__ void sf_restore(float* lds, int buf, int ls, const float* g, int C, int L) {
-    for (int i = sf_tid(); i < C * L; i += SF_T) {
-        const int ch = i / L, p = i - ch * L;
-        lds[buf + ch * ls + 4 + p] = g[i];
+// the same in two halves: up to 16 quads per thread are requested (registers) before a compute phase and written to LDS
+// after it, so the L2 / Infinity-Cache latency of the skip tensor hides behind that phase
+__device__ __forceinline__ void sf_restore_request(f32x4 (&rr)[16], const float* g, int C, int lq) {
+    const int t = sf_tid();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int i = t + SF_T * j;
+        if (i < (C << lq)) rr[j] = ((const f32x4*)g)[i];
     }
-    sf_guards(lds, buf, C, ls, L);
+}
+__device__ __forceinline__ void sf_restore_commit(const f32x4 (&rr)[16], float* lds, int buf, int ls, int C, int lq) {
+    const int t = sf_tid();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int i = t + SF_T * j;
+        if (i < (C << lq)) {
+            const int ch = i >> lq, q = i - (ch << lq);
+            *(f32x4*)(lds + buf + ch * ls + 4 + 4 * q) = rr[j];
+        }
+    }
+    sf_guards(lds, buf, C, ls, 4 << lq);
+}
+__device__ __forceinline__ void sf_restore(float* lds, int buf, int ls, const float* g, int C, int lq) {
+    for (int i = sf_tid(); i < (C << lq); i += SF_T) {
+        const int ch = i >> lq, q = i - (ch << lq);
+        *(f32x4*)(lds + buf + ch * ls + 4 + 4 * q) = ((const f32x4*)g)[i];
+    }
+    sf_guards(lds, buf, C, ls, 4 << lq);
 }
 
 struct SfArgs {
@@ -193,269 +254,329 @@ struct SfArgs {
 };
 
 #define SF_SYNC() __syncthreads()
-// request a layer's fragments now; the barrier keeps the compiler from sinking the loads to their first use
-#define SF_PREFETCH(NQ, SET, OFF) do { sf_load<NQ>(SET, blob + (OFF) + (size_t)tile_of * ((NQ) * 256), lane); \
+// diagnostic build only (scripts/stamps_stream.py, -DSF_STAMPS): cycle stamps of workgroup 0's first frame, written
+// behind the skip regions of the scratch buffer (memory nothing else in the kernel reads)
+#ifdef SF_STAMPS
+#define SF_STAMP(i) do { if (blockIdx.x == 0 && tid == 0 && n == 0) \
+    ((long long*)(A.scratch + (size_t)gridDim.x * SF_SKIP))[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SF_STAMP(i) do { } while (0)
+#endif
+
+// Every matrix layer: (1) the fragments requested one layer ago move from the staging set to the compute set,
+// (2) the NEXT layer's fragments are requested into the staging set, (3) the layer computes.  One compute set for all
+// layers keeps a single copy of every unrolled MFMA body: the kernel must stay inside the instruction cache (a first
+// version with two alternating sets and straight-line layers was 111 KB of code and ran its MFMAs at ~90 instead of 64
+// cycles each, waiting for instruction fetch).
+#define SF_TAKE(NQ) do { _Pragma("unroll") for (int i_ = 0; i_ < 4 * (NQ); ++i_) fs[i_] = fp[i_]; } while (0)
+#define SF_REQUEST(NQ, OFF, TILE) do { sf_load<NQ>(fp, blob + (OFF) + (size_t)(TILE) * ((NQ) * 256), lane); \
                                        __builtin_amdgcn_sched_barrier(0); } while (0)
+
+constexpr int LSA = sf_ls(128);          // one row stride (144 floats) for every activation buffer: immediate LDS offsets
+constexpr int LSG = sf_ls(16);           // ... except the GRU projection [384][32]
 
 __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* skip = A.scratch + (size_t)blockIdx.x * SF_SKIP;
     float* sk0 = skip, *sk1 = sk0 + 8192, *sk2 = sk1 + 16384, *sk3 = sk2 + 8192, *sk4 = sk3 + 8192;
-    float fa[176], fb[176];                      // two fragment sets (A fragments + 16 bias values of one row tile)
-    int tile_of;                                  // this wave's row tile in the layer being prefetched
+    float fs[176], fp[176];                      // compute set / staging set (A fragments + 16 bias values of one row tile)
     const int Cin = A.Cin;
 
+    // first-conv weights: resident for the whole kernel
+    sf_stage(lds, SF_W0, A.blob + A.o_first, 64 * Cin * 5 + 64);
+    // features of a frame as 5 registers per thread (zero guard / pad columns included), requested one frame ahead
+    float xr[5];
+    auto request_x = [&](int nn) __attribute__((always_inline)) {
+        constexpr int LSX = sf_ls(257);
+        const float* xg = A.x + (size_t)nn * Cin * 257;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int i = tid + SF_T * j;
+            const int ch = i / LSX, col = i - ch * LSX - 4;
+            xr[j] = (nn < A.N && ch < Cin && col >= 0 && col < 257) ? xg[ch * 257 + col] : 0.f;
+        }
+    };
+    request_x(blockIdx.x);
     for (int n = blockIdx.x; n < A.N; n += gridDim.x) {
         // The weights do not change from frame to frame, so the compiler would hoist EVERY layer's fragment loads out
         // of this loop (thousands of registers, all spilled): make the base pointer opaque once per frame.
-        const float* blob = A.blob;
-        asm volatile("" : "+s"(blob));
+        // (An opaque OFFSET, not an opaque pointer: the compiler must still see a global-memory address, or it emits
+        // flat loads, which also count on lgkmcnt and would make every LDS wait drain the weight prefetch.)
+        int opaque0 = 0;
+        asm volatile("" : "+s"(opaque0));
+        const float* blob = A.blob + opaque0;
         // ---------------- features -> LDS, first conv (C_in -> 64, k5 s2 p1) + ReLU            network.py:9-21
-        tile_of = wave;
-        SF_PREFETCH(12, fa, A.o_pw[0]);                                     // encoder.1 pw: K = 64 -> 32 k-pairs + bias
+        SF_STAMP(0);
+        SF_REQUEST(12, A.o_pw[0], wave);                                    // encoder.1 pw: K = 64 -> 32 k-pairs + bias
         {
             constexpr int LSX = sf_ls(257);
-            const float* xg = A.x + (size_t)n * Cin * 257;
-            for (int i = tid; i < Cin * LSX; i += SF_T) {
-                const int ch = i / LSX, col = i - ch * LSX - 4;
-                lds[SF_R2 + i] = (col >= 0 && col < 257) ? xg[ch * 257 + col] : 0.f;
-            }
-            sf_stage(lds, SF_R2 + 4 * LSX, blob + A.o_first, 64 * Cin * 5 + 64);
-            SF_SYNC();
-            constexpr int LS = sf_ls(128);
-            const int wb = SF_R2 + 4 * LSX;
-            for (int o = tid; o < 64 * 128; o += SF_T) {
-                const int co = o >> 7, lo = o & 127;
-                float v = lds[wb + 64 * Cin * 5 + co];
-                for (int ci = 0; ci < Cin; ++ci) {
-                    const float* in = lds + SF_R2 + ci * LSX + 4 + 2 * lo - 1;
-                    const float* w = lds + wb + (co * Cin + ci) * 5;
+            // the frame's features were requested at the end of the previous frame (xr): zero-padded rows into LDS
 #pragma unroll
-                    for (int k = 0; k < 5; ++k) v = fmaf(w[k], in[k], v);
-                }
-                lds[SF_R0 + co * LS + 4 + lo] = fmaxf(v, 0.f);
+            for (int j = 0; j < 5; ++j) {
+                const int i = tid + SF_T * j;
+                if (i < Cin * LSX) lds[SF_XB + i] = xr[j];
             }
-            sf_guards(lds, SF_R0, 64, LS, 128);
             SF_SYNC();
-            sf_save(lds, SF_R0, LS, sk0, 64, 128);
+            {
+                // thread = (position lo, half of the output channels): its C_in x 5 input window stays in registers,
+                // the weights of one output channel are a wave-uniform (broadcast) LDS read
+                const int t_ = sf_tid();
+                const int lo = t_ & 127, cg = __builtin_amdgcn_readfirstlane(t_ >> 7);
+                float xin[4][5];
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+                    for (int k = 0; k < 5; ++k)
+                        xin[ci][k] = ci < Cin ? lds[SF_XB + ci * LSX + 4 + 2 * lo - 1 + k] : 0.f;
+                for (int co = 32 * cg; co < 32 * cg + 32; co += 4) {
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = lds[SF_W0 + 64 * Cin * 5 + co + j];
+#pragma unroll
+                    for (int ci = 0; ci < 4; ++ci) {
+                        if (ci < Cin) {
+#pragma unroll
+                            for (int k = 0; k < 5; ++k)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    v[j] = fmaf(lds[SF_W0 + (co + j) * Cin * 5 + ci * 5 + k], xin[ci][k], v[j]);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) lds[SF_R0 + (co + j) * LSA + 4 + lo] = fmaxf(v[j], 0.f);
+                }
+            }
+            sf_guards(lds, SF_R0, 64, LSA, 128);
+            SF_SYNC();
+            sf_save(lds, SF_R0, LSA, sk0, 64, 5);
         }
         // ---------------- encoder.1 .. encoder.5 (pointwise + BN + ReLU, depthwise + BN + ReLU)   network.py:24-43
-        // i: (K of pw, L in, dw kernel, dw stride, L out)
+        SF_STAMP(1);
         {   // encoder.1: 64 -> 128, L 128, dw k3 s1
-            constexpr int LS = sf_ls(128);
-            sf_stage(lds, SF_R2, blob + A.o_dw[0], 128 * 4);
-            sf_pw<32, 0, 4>(fa, lds, SF_R0, LS, 0, 0, 0, SF_R1A, LS, 128, 128, 0, true);
-            sf_guards(lds, SF_R1A, 128, LS, 128);
-            SF_PREFETCH(20, fb, A.o_pw[1]);
+            float dwr[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dwr[j] = blob[A.o_dw[0] + tid + SF_T * j];
+            SF_TAKE(12);
+            SF_REQUEST(20, A.o_pw[1], wave);
+            sf_pw<32, 0, 4>(fs, lds, SF_R0, LSA, 0, 0, 0, SF_R1A, LSA, 128, 128, 0, true);
+            sf_guards(lds, SF_R1A, 128, LSA, 128);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) lds[SF_DWB + tid + SF_T * j] = dwr[j];
             SF_SYNC();
-            sf_dw(lds, SF_R1A, LS, SF_R0, LS, SF_R2, 128, 3, 1, 128);
-            sf_guards(lds, SF_R0, 128, LS, 128);
+            sf_dw<3, 1>(lds, SF_R1A, LSA, SF_R0, LSA, SF_DWB, 128, 128);
+            sf_guards(lds, SF_R0, 128, LSA, 128);
             SF_SYNC();
-            sf_save(lds, SF_R0, LS, sk1, 128, 128);
+            sf_save(lds, SF_R0, LSA, sk1, 128, 5);
         }
-        {   // encoder.2: 128 -> 128, L 128 -> 64, dw k5 s2
-            constexpr int LS = sf_ls(128), LSO = sf_ls(64);
-            sf_stage(lds, SF_R2, blob + A.o_dw[1], 128 * 6);
-            sf_pw<64, 0, 4>(fb, lds, SF_R0, LS, 0, 0, 0, SF_R1A, LS, 128, 128, 0, true);
-            sf_guards(lds, SF_R1A, 128, LS, 128);
-            SF_PREFETCH(20, fa, A.o_pw[2]);
-            SF_SYNC();
-            sf_dw(lds, SF_R1A, LS, SF_R0, LSO, SF_R2, 128, 5, 2, 64);
-            sf_guards(lds, SF_R0, 128, LSO, 64);
-            SF_SYNC();
-            sf_save(lds, SF_R0, LSO, sk2, 128, 64);
+        SF_STAMP(2);
+        // encoder.2 .. encoder.5 (128 -> 128 pointwise, then depthwise k5 s2 / k3 s1 / k5 s2 / k3 s2) and the three
+        // 128-row passes of the GRU input projection (384 x 128, both directions; network.py:45-58,149) share ONE
+        // unrolled 128 x 128 MFMA body: it = 0..3 encoder blocks, it = 4..6 projection rows 128 (it - 4) ...
+        for (int it = 0; it < 7; ++it) {
+            const bool enc = it < 4;
+            const int L = it == 0 ? 128 : (it <= 2 ? 64 : (it == 3 ? 32 : 16));      // positions of this layer's input
+            // (every iteration issues the SAME sequence of global loads, selected by offsets and not by branches: with
+            // divergent paths hipcc's s_waitcnt pass merges pessimistically at the loop header and makes the MFMAs
+            // below wait for the fragments that were only just requested for the NEXT layer)
+            float dwr[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) dwr[j] = blob[A.o_dw[enc ? 1 + it : 4] + tid + SF_T * j];
+            if (it == 1) SF_STAMP(27);
+            SF_TAKE(20);
+#ifdef SF_STAMPS
+            if (it == 1) { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); SF_STAMP(28); }
+#endif
+            {
+                const int off_ = it < 3 ? A.o_pw[2 + it] : (it < 6 ? A.o_gi : A.o_fg);      // it = 6: FGRU.conv (128 -> 64)
+                const int til_ = it < 3 ? wave : (it < 6 ? 4 * (it - 3) + wave : (wave & 1));
+                SF_REQUEST(20, off_, til_);
+            }
+            if (it == 1) SF_STAMP(29);
+            if (enc) sf_pw<64, 0, 4>(fs, lds, SF_R0, LSA, 0, 0, 0, SF_R1A, LSA, L, 128, 0, true);
+            else sf_pw<64, 0, 4>(fs, lds, SF_R0, LSA, 0, 0, 0, SF_R1A, LSG, 16, 128, 128 * (it - 4), false);
+            if (it == 1) SF_STAMP(30);
+            if (enc) {
+                sf_guards(lds, SF_R1A, 128, LSA, L);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) lds[SF_DWB + tid + SF_T * j] = dwr[j];
+                SF_SYNC();
+                if (it == 1) sf_dw<3, 1>(lds, SF_R1A, LSA, SF_R0, LSA, SF_DWB, 128, 64);
+                else if (it == 3) sf_dw<3, 2>(lds, SF_R1A, LSA, SF_R0, LSA, SF_DWB, 128, 16);
+                else sf_dw<5, 2>(lds, SF_R1A, LSA, SF_R0, LSA, SF_DWB, 128, L >> 1);
+                const int Lo = it == 1 ? 64 : (L >> 1);
+                sf_guards(lds, SF_R0, 128, LSA, Lo);
+                SF_SYNC();
+                if (it == 1) SF_STAMP(31);
+                if (it < 3) sf_save(lds, SF_R0, LSA, it == 0 ? sk2 : (it == 1 ? sk3 : sk4), 128, it == 2 ? 3 : 4);
+            }
         }
-        {   // encoder.3: L 64, dw k3 s1
-            constexpr int LS = sf_ls(64);
-            sf_stage(lds, SF_R2, blob + A.o_dw[2], 128 * 4);
-            sf_pw<64, 0, 4>(fa, lds, SF_R0, LS, 0, 0, 0, SF_R1A, LS, 64, 128, 0, true);
-            sf_guards(lds, SF_R1A, 128, LS, 64);
-            SF_PREFETCH(20, fb, A.o_pw[3]);
-            SF_SYNC();
-            sf_dw(lds, SF_R1A, LS, SF_R0, LS, SF_R2, 128, 3, 1, 64);
-            sf_guards(lds, SF_R0, 128, LS, 64);
-            SF_SYNC();
-            sf_save(lds, SF_R0, LS, sk3, 128, 64);
-        }
-        {   // encoder.4: L 64 -> 32, dw k5 s2
-            constexpr int LS = sf_ls(64), LSO = sf_ls(32);
-            sf_stage(lds, SF_R2, blob + A.o_dw[3], 128 * 6);
-            sf_pw<64, 0, 4>(fb, lds, SF_R0, LS, 0, 0, 0, SF_R1A, LS, 64, 128, 0, true);
-            sf_guards(lds, SF_R1A, 128, LS, 64);
-            SF_PREFETCH(20, fa, A.o_pw[4]);
-            SF_SYNC();
-            sf_dw(lds, SF_R1A, LS, SF_R0, LSO, SF_R2, 128, 5, 2, 32);
-            sf_guards(lds, SF_R0, 128, LSO, 32);
-            SF_SYNC();
-            sf_save(lds, SF_R0, LSO, sk4, 128, 32);
-        }
-        {   // encoder.5: L 32 -> 16, dw k3 s2
-            constexpr int LS = sf_ls(32), LSO = sf_ls(16);
-            sf_stage(lds, SF_R2, blob + A.o_dw[4], 128 * 4);
-            sf_pw<64, 0, 4>(fa, lds, SF_R0, LS, 0, 0, 0, SF_R1A, LS, 32, 128, 0, true);
-            sf_guards(lds, SF_R1A, 128, LS, 32);
-            SF_PREFETCH(20, fb, A.o_gi);                                    // GRU projection rows 0..127
-            SF_SYNC();
-            sf_dw(lds, SF_R1A, LS, SF_R0, LSO, SF_R2, 128, 3, 2, 16);
-            sf_guards(lds, SF_R0, 128, LSO, 16);
-            SF_SYNC();
-        }
-        // ---------------- FGRU: input projection (384 x 128), bidirectional recurrence over 16 positions, pw 128 -> 64
-        //                                                                                       network.py:45-58,149
+        SF_SYNC();
+#if defined(SF_ABL) && (SF_ABL & 4)      // diagnostic: encoder + projection only (does a smaller code footprint stay in the I-cache?)
+        SF_STAMP(7); SF_STAMP(23); SF_STAMP(26); SF_STAMP(8); SF_STAMP(9); SF_STAMP(13); SF_STAMP(14);
+        request_x(n + gridDim.x);
+        continue;
+#endif
         {
-            constexpr int LS = sf_ls(16);      // 32
-            tile_of = 4 + wave;
-            SF_PREFETCH(20, fa, A.o_gi);
-            tile_of = wave;
-            sf_pw<64, 0, 4>(fb, lds, SF_R0, LS, 0, 0, 0, SF_R1A, LS, 16, 128, 0, false);
-            tile_of = 8 + wave;
-            SF_PREFETCH(20, fb, A.o_gi);
-            sf_pw<64, 0, 4>(fa, lds, SF_R0, LS, 0, 0, 0, SF_R1A, LS, 16, 128, 128, false);
-            sf_pw<64, 0, 4>(fb, lds, SF_R0, LS, 0, 0, 0, SF_R1A, LS, 16, 128, 256, false);
-            tile_of = wave & 1;
-            SF_PREFETCH(20, fa, A.o_fg);                                    // FGRU.conv: 128 -> 64
-            SF_SYNC();
-            // recurrence: direction d = tid >> 7, thread u owns rows u and (u < 64) 128 + u of W_hh[d] (r | z | n)
-            const int d = tid >> 7, u = tid & 127;
-            const float* whh = blob + A.o_whh + (size_t)d * 192 * 64;
-            const float* bhh = blob + A.o_whh + 2 * 192 * 64 + d * 192;
-            float wA[64], wB[64];
+            SF_STAMP(7);
+            // recurrence: direction d = tid >> 7; thread u owns row u of W_hh[d] (r | z rows) and one K-half of row
+            // 128 + (u & 63) (the n rows): 96 multiply-adds per thread and step, weights in registers for all 16 steps
+            const int t_ = sf_tid();
+            const int d = t_ >> 7, u = t_ & 127, kh = (u >> 6) * 32;
+            // exporter layout: [direction][24 quads][128 threads][4]: quads 0..15 = row u, 16..23 = this thread's K-half of
+            // row 128 + (u & 63); then b_hh [2][192] -- every load is 16 bytes per lane, consecutive lanes consecutive
+            const f32x4* whh = (const f32x4*)(blob + A.o_whh) + (size_t)d * 24 * 128 + u;
+            const float* bhh = blob + A.o_whh + 2 * 24 * 128 * 4 + d * 192;
+            float wA[64], wB[32];
             const int rowB = 128 + (u & 63);
 #pragma unroll
-            for (int k = 0; k < 64; k += 4) {
-                const f32x4 ta = *(const f32x4*)(whh + u * 64 + k);
-                const f32x4 tb = *(const f32x4*)(whh + rowB * 64 + k);
+            for (int q = 0; q < 16; ++q) {
+                const f32x4 ta = whh[q * 128];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { wA[k + e] = ta[e]; wB[k + e] = tb[e]; }
+                for (int e = 0; e < 4; ++e) wA[4 * q + e] = ta[e];
             }
-            const float bA = bhh[u], bB = bhh[rowB];
-            float* hs = lds + SF_R2 + d * 64;               // h of this direction
-            float* ghs = lds + SF_R2 + 128 + d * 192;       // W_hh h + b_hh
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x4 tb = whh[(16 + q) * 128];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wB[4 * q + e] = tb[e];
+            }
+            // opaque copies: the compiler must keep them in registers instead of re-loading them from memory every step
+#pragma unroll
+            for (int k = 0; k < 64; ++k) asm volatile("" : "+v"(wA[k]));
+#pragma unroll
+            for (int k = 0; k < 32; ++k) asm volatile("" : "+v"(wB[k]));
+            const float bA = bhh[u], bB = (u < 64) ? bhh[rowB] : 0.f;
+            float* hs = lds + SF_GRU + d * 64;               // h of this direction
+            float* ghs = lds + SF_GRU + 128 + d * 256;       // [0,128): r | z rows, [128,192) and [192,256): halves of n
             if (u < 64) hs[u] = 0.f;
             SF_SYNC();
+            SF_STAMP(23);
             for (int st = 0; st < 16; ++st) {
                 const int pos = d ? 15 - st : st;
-                float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+                f32x4 hv[16];
 #pragma unroll
-                for (int k = 0; k < 64; k += 4) {
-                    const f32x4 hv = *(const f32x4*)(hs + k);
-                    a0 = fmaf(wA[k], hv[0], a0); a1 = fmaf(wA[k + 1], hv[1], a1);
-                    a0 = fmaf(wA[k + 2], hv[2], a0); a1 = fmaf(wA[k + 3], hv[3], a1);
-                    b0 = fmaf(wB[k], hv[0], b0); b1 = fmaf(wB[k + 1], hv[1], b1);
-                    b0 = fmaf(wB[k + 2], hv[2], b0); b1 = fmaf(wB[k + 3], hv[3], b1);
+                for (int i = 0; i < 16; ++i) hv[i] = *(const f32x4*)(hs + 4 * i);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    a0 = fmaf(wA[4 * i], hv[i][0], a0); a1 = fmaf(wA[4 * i + 1], hv[i][1], a1);
+                    a2 = fmaf(wA[4 * i + 2], hv[i][2], a2); a3 = fmaf(wA[4 * i + 3], hv[i][3], a3);
                 }
-                ghs[u] = a0 + a1 + bA;
-                if (u < 64) ghs[rowB] = b0 + b1 + bB;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    // K-half kh = 0 or 32: hv[i] or hv[8 + i] (a select on registers, no second LDS read)
+                    f32x4 hh;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hh[e] = kh ? hv[8 + i][e] : hv[i][e];
+                    b0 = fmaf(wB[4 * i], hh[0], b0); b1 = fmaf(wB[4 * i + 1], hh[1], b1);
+                    b2 = fmaf(wB[4 * i + 2], hh[2], b2); b3 = fmaf(wB[4 * i + 3], hh[3], b3);
+                }
+                ghs[u] = (a0 + a1) + (a2 + a3) + bA;
+                ghs[128 + u] = (b0 + b1) + (b2 + b3) + bB;
                 SF_SYNC();
                 if (u < 64) {
-                    const float* gi = lds + SF_R1A + (d * 192 + u) * LS + 4 + pos;
+                    const float* gi = lds + SF_R1A + (d * 192 + u) * LSG + 4 + pos;
                     const float r = sf_sigmoid(gi[0] + ghs[u]);
-                    const float z = sf_sigmoid(gi[64 * LS] + ghs[64 + u]);
-                    const float nn = sf_tanh(fmaf(r, ghs[128 + u], gi[128 * LS]));
+                    const float z = sf_sigmoid(gi[64 * LSG] + ghs[64 + u]);
+                    const float nn = sf_tanh(fmaf(r, ghs[128 + u] + ghs[192 + u], gi[128 * LSG]));
                     const float hn = (1.f - z) * nn + z * hs[u];
-                    lds[SF_R0 + (d * 64 + u) * LS + 4 + pos] = hn;
+                    lds[SF_R0 + (d * 64 + u) * LSA + 4 + pos] = hn;
                     hs[u] = hn;
                 }
                 SF_SYNC();
+                if (st == 0) SF_STAMP(24);
+                if (st == 8) SF_STAMP(25);
             }
-            sf_guards(lds, SF_R0, 128, LS, 16);
+            SF_STAMP(26);
+            sf_guards(lds, SF_R0, 128, LSA, 16);
             SF_SYNC();
-            sf_pw<64, 0, 2>(fa, lds, SF_R0, LS, 0, 0, 0, SF_R1A, LS, 16, 64, 0, true);
-            sf_guards(lds, SF_R1A, 64, LS, 16);
-            SF_PREFETCH(12, fb, A.o_dpw[0]);                                // decoder.0 pw: 64 -> 64
+            SF_STAMP(8);
+            // FGRU.conv (128 -> 64) + BN + ReLU
+            SF_TAKE(20);
+            SF_REQUEST(12, A.o_dpw[0], wave & 1);                             // decoder.0 pw: 64 -> 64
+            sf_pw<64, 0, 2>(fs, lds, SF_R0, LSA, 0, 0, 0, SF_R1A, LSA, 16, 64, 0, true);
+            sf_guards(lds, SF_R1A, 64, LSA, 16);
             SF_SYNC();
             // ---------------- decoder.0 (FirstTrCNN): pw 64 -> 64, ConvT k3 s2 -> L 31            network.py:60-76
-            sf_pw<32, 0, 2>(fb, lds, SF_R1A, LS, 0, 0, 0, SF_R1B, LS, 16, 64, 0, true);
-            sf_guards(lds, SF_R1B, 64, LS, 16);
-            SF_PREFETCH(28, fa, A.o_ct[0]);
+            SF_TAKE(12);
+            SF_REQUEST(28, A.o_ct[0], wave & 1);
+            sf_pw<32, 0, 2>(fs, lds, SF_R1A, LSA, 0, 0, 0, SF_R1B, LSA, 16, 64, 0, true);
+            sf_guards(lds, SF_R1B, 64, LSA, 16);
             SF_SYNC();
-            sf_restore(lds, SF_R0, sf_ls(32), sk4, 128, 32);
-            SF_PREFETCH(28, fb, A.o_dpw[1]);                                // decoder.1 pw: 192 -> 64
-            sf_convT<3, 2>(fa, lds, SF_R1B, LS, SF_R1A, sf_ls(31), 31);
-            sf_guards(lds, SF_R1A, 64, sf_ls(31), 31);
+            sf_restore(lds, SF_R0, LSA, sk4, 128, 3);
+            SF_TAKE(28);
+            SF_REQUEST(28, A.o_dpw[1], wave & 1);                             // decoder.1 pw: 192 -> 64
+            sf_convT<3, 2>(fs, lds, SF_R1B, LSA, SF_R1A, LSA, 31);
+            sf_guards(lds, SF_R1A, 64, LSA, 31);
             SF_SYNC();
         }
         // ---------------- decoder.1 .. decoder.4 (TrCNN): [x1 padded / cropped | skip] -> pw 192 -> 64 -> ConvT
         //                                                                                       network.py:79-100
-        {   // decoder.1: x1 L 31 (pad right 1), skip enc4 L 32, ConvT k5 s2 -> 65
-            constexpr int LSX = sf_ls(31), LS = sf_ls(32), LSO = sf_ls(65);
-            sf_pw<32, 64, 2>(fb, lds, SF_R1A, LSX, 0, SF_R0, LS, SF_R1B, LS, 32, 64, 0, true);
-            sf_guards(lds, SF_R1B, 64, LS, 32);
-            SF_PREFETCH(44, fa, A.o_ct[1]);
+        // one loop body for the four blocks: i = 1: x1 L 31 (pad right 1), skip enc4 L 32, ConvT k5 s2 -> 65;
+        // i = 2: x1 65 (crop left 1), skip enc3 L 64, k3 s1 -> 66;  i = 3: x1 66 (crop 1 each side), skip enc2 L 64,
+        // k5 s2 -> 129;  i = 4: x1 129 (crop left 1), skip enc1 L 128, k3 s1 -> 130.  The next block's skip tensor is
+        // restored into R0 while this block's ConvT runs.
+        SF_STAMP(9);
+        for (int i = 1; i <= 4; ++i) {
+            const int P = i == 1 ? 32 : (i == 4 ? 128 : 64);
+            const int Lo = i == 1 ? 65 : (i == 2 ? 66 : (i == 3 ? 129 : 130));
+            SF_TAKE(28);
+            // same load sequence in every iteration (see the encoder loop): 44 quads are requested also for the 3-tap
+            // layers (28 used; the tile stride in the blob is that of the layer's own fragment count)
+            sf_load<44>(fp, blob + A.o_ct[i] + (size_t)(wave & 1) * (((i & 1) ? 44 : 28) * 256), lane);
+            __builtin_amdgcn_sched_barrier(0);
+            sf_pw<32, 64, 2>(fs, lds, SF_R1A, LSA, i == 1 ? 0 : 1, SF_R0, LSA, SF_R1B, LSA, P, 64, 0, true);
+            sf_guards(lds, SF_R1B, 64, LSA, P);
             SF_SYNC();
-            sf_restore(lds, SF_R0, sf_ls(64), sk3, 128, 64);
-            SF_PREFETCH(28, fb, A.o_dpw[2]);
-            sf_convT<5, 2>(fa, lds, SF_R1B, LS, SF_R1A, LSO, 65);
-            sf_guards(lds, SF_R1A, 64, LSO, 65);
-            SF_SYNC();
-        }
-        {   // decoder.2: x1 L 65 (crop left 1), skip enc3 L 64, ConvT k3 s1 -> 66
-            constexpr int LSX = sf_ls(65), LS = sf_ls(64), LSO = sf_ls(66);
-            sf_pw<32, 64, 2>(fb, lds, SF_R1A, LSX, 1, SF_R0, LS, SF_R1B, LS, 64, 64, 0, true);
-            sf_guards(lds, SF_R1B, 64, LS, 64);
-            SF_PREFETCH(28, fa, A.o_ct[2]);
-            SF_SYNC();
-            sf_restore(lds, SF_R0, sf_ls(64), sk2, 128, 64);
-            SF_PREFETCH(28, fb, A.o_dpw[3]);
-            sf_convT<3, 1>(fa, lds, SF_R1B, LS, SF_R1A, LSO, 66);
-            sf_guards(lds, SF_R1A, 64, LSO, 66);
-            SF_SYNC();
-        }
-        {   // decoder.3: x1 L 66 (crop 1 each side), skip enc2 L 64, ConvT k5 s2 -> 129
-            constexpr int LSX = sf_ls(66), LS = sf_ls(64), LSO = sf_ls(129);
-            sf_pw<32, 64, 2>(fb, lds, SF_R1A, LSX, 1, SF_R0, LS, SF_R1B, LS, 64, 64, 0, true);
-            sf_guards(lds, SF_R1B, 64, LS, 64);
-            SF_PREFETCH(44, fa, A.o_ct[3]);
-            SF_SYNC();
-            sf_restore(lds, SF_R0, sf_ls(128), sk1, 128, 128);
-            SF_PREFETCH(28, fb, A.o_dpw[4]);
-            sf_convT<5, 2>(fa, lds, SF_R1B, LS, SF_R1A, LSO, 129);
-            sf_guards(lds, SF_R1A, 64, LSO, 129);
+            // skip tensor of the next block: enc3 (L 64), enc2 (L 64), enc1 (L 128), enc0 (64 x 128): requested now,
+            // written to R0 after the ConvT (R0's current content, this block's skip, was last read before the barrier)
+            f32x4 rr[16];
+            const float* skn = i == 1 ? sk3 : (i == 2 ? sk2 : (i == 3 ? sk1 : sk0));
+            const int skC = i == 4 ? 64 : 128, sklq = i <= 2 ? 4 : 5;
+            sf_restore_request(rr, skn, skC, sklq);
+            SF_TAKE(44);
+            // next pw: decoder.(i+1) 192 -> 64 (28 quads per tile), or decoder.5 128 -> 8 (one padded tile of 20 quads)
+            sf_load<28>(fp, blob + A.o_dpw[i + 1] + (size_t)(i < 4 ? (wave & 1) : 0) * (28 * 256), lane);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i & 1) sf_convT<5, 2>(fs, lds, SF_R1B, LSA, SF_R1A, LSA, Lo);
+            else sf_convT<3, 1>(fs, lds, SF_R1B, LSA, SF_R1A, LSA, Lo);
+            sf_restore_commit(rr, lds, SF_R0, LSA, skC, sklq);
+            sf_guards(lds, SF_R1A, 64, LSA, Lo);
             SF_SYNC();
         }
-        {   // decoder.4: x1 L 129 (crop left 1), skip enc1 L 128, ConvT k3 s1 -> 130
-            constexpr int LSX = sf_ls(129), LS = sf_ls(128), LSO = sf_ls(130);
-            sf_pw<32, 64, 2>(fb, lds, SF_R1A, LSX, 1, SF_R0, LS, SF_R1B, LS, 128, 64, 0, true);
-            sf_guards(lds, SF_R1B, 64, LS, 128);
-            SF_PREFETCH(28, fa, A.o_ct[4]);
-            SF_SYNC();
-            sf_restore(lds, SF_R0, sf_ls(128), sk0, 64, 128);
-            tile_of = 0;
-            SF_PREFETCH(20, fb, A.o_dpw[5]);                                // decoder.5 pw: 128 -> 8 (one padded row tile)
-            tile_of = wave & 1;
-            sf_convT<3, 1>(fa, lds, SF_R1B, LS, SF_R1A, LSO, 130);
-            sf_guards(lds, SF_R1A, 64, LSO, 130);
-            SF_SYNC();
-        }
+        SF_STAMP(13);
         {   // ---------------- decoder.5 (LastTrCNN): pw 128 -> 8 (+BN+ReLU), ConvT 8 -> 8 k5 s2 -> 257, linear
             //                                                                                   network.py:102-120
-            constexpr int LSX = sf_ls(130), LS = sf_ls(128);
-            sf_pw<32, 32, 1>(fb, lds, SF_R1A, LSX, 1, SF_R0, LS, SF_R1B, LS, 128, 8, 0, true);
-            sf_guards(lds, SF_R1B, 8, LS, 128);
-            sf_stage(lds, SF_R2, blob + A.o_last, 8 * 8 * 5 + 8);        // [ci][co][k], bias
+            SF_TAKE(20);
+            sf_pw<32, 32, 1>(fs, lds, SF_R1A, LSA, 1, SF_R0, LSA, SF_R1B, LSA, 128, 8, 0, true);
+            sf_guards(lds, SF_R1B, 8, LSA, 128);
+            sf_stage(lds, SF_DWB, blob + A.o_last, 8 * 8 * 5 + 8);       // [ci][co][k], bias
+            request_x(n + gridDim.x);                                       // next frame's features, in flight over the tail
             SF_SYNC();
             float* yg = A.y + (size_t)n * 8 * 257;
             for (int o = tid; o < 8 * 257; o += SF_T) {
                 const int co = o / 257, p = o - co * 257;
-                float v = lds[SF_R2 + 320 + co];
+                float v = lds[SF_DWB + 320 + co];
                 // taps with (p + 1 - k) even: k = (p + 1) & 1, +2, +4; source position (p + 1 - k) / 2
                 for (int k = (p + 1) & 1; k < 5; k += 2) {
                     const int q = (p + 1 - k) >> 1;              // guards cover q = -1 and q = 128
                     const float* in = lds + SF_R1B + 4 + q;
 #pragma unroll
-                    for (int ci = 0; ci < 8; ++ci) v = fmaf(lds[SF_R2 + (ci * 8 + co) * 5 + k], in[ci * LS], v);
+                    for (int ci = 0; ci < 8; ++ci) v = fmaf(lds[SF_DWB + (ci * 8 + co) * 5 + k], in[ci * LSA], v);
                 }
                 yg[o] = v;
             }
             SF_SYNC();
         }
+        SF_STAMP(14);
     }
 }
 
 }  // namespace
 
-extern "C" size_t trunet_stream_fwd_scratch_floats(int grid) { return (size_t)grid * SF_SKIP; }
+extern "C" size_t trunet_stream_fwd_scratch_floats(int grid) { return (size_t)grid * SF_SKIP + 64; }
 extern "C" int trunet_stream_fwd_grid(int N) { return N < 2 * TRUNET_NUM_CU ? (N < TRUNET_NUM_CU ? N : TRUNET_NUM_CU) : TRUNET_NUM_CU; }
 
 extern "C" int trunet_stream_fwd(const float* x, float* y, const float* blob, const int32_t* h_offsets, int n_offsets,

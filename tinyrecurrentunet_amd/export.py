@@ -80,8 +80,15 @@ def fold(net):
     Wih = np.concatenate([t(g.weight_ih_l0), t(g.weight_ih_l0_reverse)], 0)
     bih = np.concatenate([t(g.bias_ih_l0), t(g.bias_ih_l0_reverse)], 0)
     add(_frag_tiles(Wih, bih))                                                         # o_gi
-    add(np.concatenate([t(g.weight_hh_l0).reshape(-1), t(g.weight_hh_l0_reverse).reshape(-1), t(g.bias_hh_l0),
-                        t(g.bias_hh_l0_reverse)]))                                     # o_whh
+    # recurrence weights in the order the kernel's threads read them: [direction][24 quads][128 threads][4]; thread u owns
+    # row u (quads 0..15) and the K-half (u >> 6) of row 128 + (u & 63) (quads 16..23); then b_hh of both directions
+    whh = []
+    for W in (t(g.weight_hh_l0), t(g.weight_hh_l0_reverse)):
+        u = np.arange(128)
+        rows = W[u].reshape(128, 16, 4).transpose(1, 0, 2)                                       # (16, 128, 4)
+        half = np.stack([W[128 + (i & 63), 32 * (i >> 6):32 * (i >> 6) + 32] for i in u])      # (128, 32)
+        whh.append(np.concatenate([rows, half.reshape(128, 8, 4).transpose(1, 0, 2)], 0).reshape(-1))
+    add(np.concatenate(whh + [t(g.bias_hh_l0), t(g.bias_hh_l0_reverse)]))                          # o_whh
     sc, sh = _bn_affine(net.FGRU.conv[1])
     fc = net.FGRU.conv[0]
     add(_frag_tiles(t(fc.weight)[:, :, 0] * sc.numpy()[:, None], t(fc.bias) * sc.numpy() + sh.numpy()))   # o_fg
@@ -104,6 +111,7 @@ def fold(net):
         add(a)                                                                         # o_ct[5]
     add(last)                                                                          # o_last
     assert len(offs) == 26
+    sec.append(np.zeros(64 * 256))         # the kernel requests fixed-size fragment blocks: over-reads stay inside the blob
     return np.concatenate(sec).astype(np.float32), np.array(offs, dtype=np.int32), cin
 
 
