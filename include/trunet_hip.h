@@ -149,6 +149,30 @@ typedef struct {
 int trunet_pw_bwd_nparts(void);
 int trunet_pw_bwd(const trunet_pwbwd_args* h_args, void* stream);
 
+/* Fused backward of a ConvTranspose1d(64 -> 64, k, stride s, padding s/2) + BatchNorm layer whose input is the
+ * BatchNorm+ReLU of a raw tensor `src` (autograd of network.py:67,86 between the BatchNorms of :65,84 and :72,91): ONE pass
+ * over (dy, z, src) instead of trunet_conv_wgrad + trunet_conv_gemm over K tap segments each.
+ *   dz = ca dy + cb z + cc;   dW[ci][co][k] = sum_{q,n<N} a[ci][q][n] dz[co][q s - pad + k][n],  a = max(s_scale src + s_shift, 0)
+ *   db[co] = sum_{p,n} dz;    dsrc[ci][q][n] = [a > 0] sum_{co,k} W[ci][co][k] dz[co][q s - pad + k][n]
+ *   partials[trunet_convt_bwd_nparts()][Ci][2] = sum dsrc, sum dsrc (src - s_mean)   (for trunet_bn_finalize_bwd)
+ * w_partials / b_partials: per-workgroup partial images as for trunet_conv_wgrad (image stride w_numel, native
+ * (Ci, Co, K) weight layout; trunet_convt_bwd_nparts() == trunet_conv_wgrad_nparts() images).
+ * TRUNET_ENOTSUP unless Ci = Co = 64 and (k, s) in {(3,1), (3,2), (5,2)} (decoder.0 .. decoder.4). */
+typedef struct {
+    int32_t NP, N, Lin, Lout, K, S, pad, Ci, Co;
+    int32_t w_numel, b_stride, b_off;
+    const float* dy; const float* z;                   /* [Co][Lout][NP] */
+    const float* ca; const float* cb; const float* cc; /* [Co] BatchNorm-backward coefficients of z */
+    const float* src;                                  /* [Ci][Lin][NP] raw tensor in front of the layer's BatchNorm+ReLU */
+    const float* s_scale; const float* s_shift; const float* s_mean;   /* [Ci] */
+    const float* W;                                    /* (Ci, Co, K) */
+    float* dsrc;                                       /* [Ci][Lin][NP] */
+    float* partials;                                   /* [nparts][Ci][2] */
+    float* w_partials; float* b_partials;
+} trunet_convt_bwd_args;
+int trunet_convt_bwd_nparts(void);
+int trunet_convt_bwd(const trunet_convt_bwd_args* h_args, void* stream);
+
 /* out[i] (+)= sum_g partials[g][i]  (deterministic second stage of every split reduction) */
 int trunet_reduce_partials(float* out, const float* partials, int nparts, int numel, int accumulate,
                            void* stream);

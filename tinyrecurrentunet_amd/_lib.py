@@ -56,6 +56,13 @@ class PwBwdArgs(C.Structure):
     _fields_ = [("w", WgradArgs), ("W", _fp), ("dg", DgradOut * MAX_SEG)]
 
 
+class ConvtBwdArgs(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("NP", "N", "Lin", "Lout", "K", "S", "pad", "Ci", "Co", "w_numel", "b_stride",
+                                         "b_off")] + \
+               [(n, _fp) for n in ("dy", "z", "ca", "cb", "cc", "src", "s_scale", "s_shift", "s_mean", "W", "dsrc", "partials",
+                                   "w_partials", "b_partials")]
+
+
 _lib = None
 
 
@@ -83,6 +90,8 @@ def _declare(L):
         "trunet_conv_gemm_plan": [C.POINTER(GemmArgs)] + [C.POINTER(C.c_int)] * 6,
         "trunet_conv_wgrad_nparts": [],
         "trunet_conv_wgrad": [C.POINTER(WgradArgs), p],
+        "trunet_convt_bwd_nparts": [],
+        "trunet_convt_bwd": [C.POINTER(ConvtBwdArgs), p],
         "trunet_pw_bwd_nparts": [],
         "trunet_pw_bwd": [C.POINTER(PwBwdArgs), p],
         "trunet_reduce_partials": [p, p, i, i, i, p],

@@ -16,7 +16,7 @@ from . import _lib as L
 import os
 
 from ._lib import (DG_ACCUM, DG_MASK, DG_STATS, DG_STORE, EPI_ACCUM, EPI_BIAS, EPI_MASK, EPI_STATS, PRO_BNBWD,
-                   PRO_BNRELU, PRO_NONE, GemmArgs, PwBwdArgs, WgradArgs, check, make_seg, ptr)
+                   PRO_BNRELU, PRO_NONE, ConvtBwdArgs, GemmArgs, PwBwdArgs, WgradArgs, check, make_seg, ptr)
 
 F_BINS = 257
 FRAME_PAD = 256      # frames are padded to a multiple of 256 (widest conv_gemm tile)
@@ -29,6 +29,10 @@ BN_MOM = 0.1
 FUSED_PWBWD = os.environ.get("TRUNET_FUSED_PWBWD", "1") != "0"
 
 FUSED_THIN = os.environ.get("TRUNET_FUSED_THIN", "0") == "1"
+
+# Backward of the 64 -> 64 transposed convs (decoder.0 .. decoder.4): one fused launch (trunet_convt_bwd) instead of
+# trunet_conv_wgrad + trunet_conv_gemm over the tap segments; TRUNET_FUSED_CONVT=0 keeps the separate launches.
+FUSED_CONVT = os.environ.get("TRUNET_FUSED_CONVT", "1") != "0"
 
 # TGRU time loop as a host loop of (GEMM, cell) launch pairs instead of the persistent kernels (A/B, other H)
 TGRU_LOOP = os.environ.get("TRUNET_TGRU_LOOP", "0") == "1"
@@ -873,17 +877,18 @@ class TRUNetEngine:
         dy, z, bn = up
         k, s_, pad = ct.kernel_size[0], ct.stride[0], ct.padding[0]
         Ci, Co = ct.in_channels, ct.out_channels
-        # transposed conv: weight/bias gradient
-        self._wgrad(w, N=N, NP=NP, P=Lo, M=Co, dz=dy, dz1=z, dz_L=Lo, dz_bn=bn, W=ct.weight, ldw_m=k,
-                    ldw_c=Co * k, segs=[a_pw.seg(pos_off=pad - kk, woff=kk, pos_div=s_) for kk in range(k)],
-                    grads=grads, bias=ct.bias)
-        # transposed conv: data gradient -> dy of the pw BN (+ stats)
         dy_pw = w.get(dy_pw_name, (Ci, a_pw.L, NP))
-        segs = [self._dz_seg(dy, z, bn, Co, Lo, pos_mul=s_, pos_off=kk - pad, woff=kk) for kk in range(k)]
-        nparts = self._gemm(w, N=N, NP=NP, P=a_pw.L, M=Ci, out=dy_pw, out_L=a_pw.L, W=ct.weight.data,
-                            ldw_m=Co * k, ldw_c=k, segs=segs, zmask=a_pw.t, e0=a_pw.bn.scale, e1=a_pw.bn.shift,
-                            e2=a_pw.bn.mean, stats=Ci)
-        self._bn_bwd(w, a_pw.bn, nparts, grads)
+        if not (FUSED_CONVT and bn is not None and self._convt_bwd(w, N, NP, ct, a_pw, Lo, dy, z, bn, dy_pw, grads)):
+            # transposed conv: weight/bias gradient
+            self._wgrad(w, N=N, NP=NP, P=Lo, M=Co, dz=dy, dz1=z, dz_L=Lo, dz_bn=bn, W=ct.weight, ldw_m=k,
+                        ldw_c=Co * k, segs=[a_pw.seg(pos_off=pad - kk, woff=kk, pos_div=s_) for kk in range(k)],
+                        grads=grads, bias=ct.bias)
+            # transposed conv: data gradient -> dy of the pw BN (+ stats)
+            segs = [self._dz_seg(dy, z, bn, Co, Lo, pos_mul=s_, pos_off=kk - pad, woff=kk) for kk in range(k)]
+            nparts = self._gemm(w, N=N, NP=NP, P=a_pw.L, M=Ci, out=dy_pw, out_L=a_pw.L, W=ct.weight.data,
+                                ldw_m=Co * k, ldw_c=k, segs=segs, zmask=a_pw.t, e0=a_pw.bn.scale, e1=a_pw.bn.shift,
+                                e2=a_pw.bn.mean, stats=Ci)
+            self._bn_bwd(w, a_pw.bn, nparts, grads)
         # pointwise conv over [x1 | skip]
         Lp = a_pw.L
         srcs = [x1.seg(pos_off=-left, woff=0)] + ([skip.seg(woff=x1.C)] if skip is not None else [])
@@ -901,6 +906,38 @@ class TRUNetEngine:
         fused = FUSED_PWBWD and (pw.out_channels % 32 == 0 or (pw.out_channels <= 8 and FUSED_THIN))
         self._pw_bwd(w, N=N, NP=NP, P=Lp, M=pw.out_channels, dz=dy_pw, dz1=a_pw.t, dz_bn=a_pw.bn, W=pw.weight,
                      bias=pw.bias, segs=srcs, outs=outs, grads=grads, fused=fused)
+
+    def _convt_bwd(self, w, N, NP, ct, a_pw, Lo, dy, z, bn, dy_pw, grads):
+        """Fused backward of ConvTranspose1d(64 -> 64) + BatchNorm (trunet_convt_bwd): weight / bias gradient, the data
+        gradient at the pointwise BatchNorm's output (masked) and its BatchNorm-backward sums in one pass over (dy, z,
+        source).  False when the kernel does not support the layer (TRUNET_ENOTSUP): the caller takes the separate launches."""
+        lib = L.lib()
+        k, s_, pad = ct.kernel_size[0], ct.stride[0], ct.padding[0]
+        a = ConvtBwdArgs()
+        a.NP, a.N, a.Lin, a.Lout, a.K, a.S, a.pad = NP, N, a_pw.L, Lo, k, s_, pad
+        a.Ci, a.Co = ct.in_channels, ct.out_channels
+        if a.Ci != 64 or a.Co != 64:
+            return False
+        nparts = lib.trunet_convt_bwd_nparts()
+        part = w.flat("ct_partials", nparts * a.Ci * 2)
+        a.dy, a.z = ptr(dy), ptr(z)
+        a.ca, a.cb, a.cc = ptr(bn.ca), ptr(bn.cb), ptr(bn.cc)
+        a.src, a.s_scale, a.s_shift, a.s_mean = ptr(a_pw.t), ptr(a_pw.bn.scale), ptr(a_pw.bn.shift), ptr(a_pw.bn.mean)
+        a.W, a.dsrc, a.partials = ptr(ct.weight.data), ptr(dy_pw), ptr(part)
+        a.w_numel = self._wg_total
+        a.w_partials, a.b_partials = self._wg_slot(ct.weight), self._wg_slot(ct.bias)
+        a.b_stride, a.b_off = self._wg_total, 0
+        if PROFILE is not None:
+            fl = 4.0 * N * a.Ci * a.Co * sum(1 for q in range(a_pw.L) for kk in range(k) if 0 <= q * s_ - pad + kk < Lo)
+            with _Timed("convt_bwd_kernel<%d, %d>" % (k, s_), fl, "L%d" % a_pw.L):
+                rc = lib.trunet_convt_bwd(a, L.stream())
+        else:
+            rc = lib.trunet_convt_bwd(a, L.stream())
+        if rc == L.TRUNET_ENOTSUP:
+            return False
+        check(rc, "convt_bwd")
+        self._bn_bwd(w, a_pw.bn, nparts, grads, part_name="ct_partials")
+        return True
 
     def _bwd_fgru(self, w, N, NP, blk, up, hout, src, src_mask, dy_src, grads):
         """GRUBlock(128, 64, 64, True) (network.py:45-58): pointwise conv over hout, the recurrence, the input
