@@ -221,6 +221,9 @@ def main():
     ap.add_argument("--streaming", action="store_true",
                     help="BASELINE.json configs[3]: 1-frame causal forward of 1024 concurrent streams (rt.py protocol)")
     args = ap.parse_args()
+    if args.dtype != "f32":
+        raise SystemExit("bench.py --dtype bf16: the bf16 storage / MFMA family (BASELINE.json configs[2]) is not built "
+                         "(DESIGN.md section 7); every kernel computes fp32, which is configs[1], the headline metric")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
