@@ -80,6 +80,27 @@ def main():
                        "MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts half of wide streaming reads)",
                "hbm_bytes_per_step": per_step, "kernels": ker},
               open(os.path.join(ROOT, "profiles", name + "_pmc_traffic.json"), "w"), indent=1)
+    # matrix-pipe / wait fractions per kernel from the SQ pass (one more rocprofv3 --pmc run):
+    #   mfma_pipe_busy = SQ_VALU_MFMA_BUSY_CYCLES / (32 * SQ_BUSY_CYCLES)   (32 SIMDs behind one SQ counter instance)
+    #   wave_parked = SQ_WAIT_ANY / SQ_WAVE_CYCLES, wave_issue_stalled = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES
+    sq = {}
+    names = ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
+             "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT")
+    cs = {nm: counters(os.path.join(src, "sq"), nm) for nm in names}
+    for k in cs["SQ_BUSY_CYCLES"]:
+        v = {nm: cs[nm].get(k, [0, 0.0])[1] for nm in names}
+        if v["SQ_BUSY_CYCLES"] <= 0 or v["SQ_WAVE_CYCLES"] <= 0:
+            continue
+        sq[k] = {"launches": cs["SQ_BUSY_CYCLES"][k][0],
+                 "mfma_pipe_busy": round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (32.0 * v["SQ_BUSY_CYCLES"]), 4),
+                 "wave_parked": round(v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], 4),
+                 "wave_issue_stalled": round(v["SQ_WAIT_INST_ANY"] / v["SQ_WAVE_CYCLES"], 4),
+                 "wave_issuing": round(v["SQ_ACTIVE_INST_ANY"] / v["SQ_WAVE_CYCLES"], 4),
+                 "lds_bank_conflict_cycles": v["SQ_LDS_BANK_CONFLICT"]}
+    if sq:
+        json.dump({"note": "rocprofv3 --pmc SQ_* pass over `bench.py --steps 1 --warmup 1`; see scripts/summarize_profile.py "
+                           "for the ratios", "kernels": dict(sorted(sq.items(), key=lambda kv: -kv[1]["mfma_pipe_busy"]))},
+                  open(os.path.join(ROOT, "profiles", name + "_pmc_sq.json"), "w"), indent=1)
     print("step total %.1f ms, HBM %.1f GB/step" % (tot / 1e6 / steps, per_step / 1e9))
 
 

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_kernel(const float* __restrict
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int d = wave >> 1, jt = wave & 1;
-    const int h = lane >> 5, c = lane & 31;
+    const int h0 = lane >> 5, c0 = lane & 31;
     const float* whh = d ? whh1 : whh0;
     const float* bhh = d ? bhh1 : bhh0;
     const int n0 = blockIdx.x * GF;
@@ -45,15 +45,18 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_kernel(const float* __restrict
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int kk = 0; kk < 32; ++kk) A[g][kk] = whh[(size_t)(g * H + 32 * jt + c) * H + 2 * kk + h];
+        for (int kk = 0; kk < 32; ++kk) A[g][kk] = whh[(size_t)(g * H + 32 * jt + c0) * H + 2 * kk + h0];
 
-    float hprev[16][2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { hprev[r][0] = 0.f; hprev[r][1] = 0.f; }
-
+    // Register budget: 96 A-fragment + 96 accumulator registers are fixed.  (1) h_{t-1} of this lane's (unit, frame)
+    // pairs is re-read from the LDS exchange buffer in the gate phase instead of living in 32 registers across the MFMA
+    // loop; (2) the per-lane part of every global address is re-derived from an opaque copy of the lane index inside the
+    // step loop: hipcc otherwise hoists ~80 loop-invariant 64-bit row addresses (gi, hout, gates) out of the loop and
+    // spills (round 1: 76 VGPRs, 304 B of scratch per lane).
     for (int t = 0; t < L; ++t) {
         const int pos = d ? (L - 1 - t) : t;
         const int buf = t & 1;
+        int c = c0, h = h0;
+        asm volatile("" : "+v"(c), "+v"(h));
         f32x16 acc[3][2];
         float gin[16][2];
         // seed accumulators with gi (+ b_hh); keep gi_n aside, gh_n accumulates on b_hn alone
@@ -81,18 +84,20 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_kernel(const float* __restrict
             }
         }
         float* hw = &hs[d][buf][0][0];
+        const float* hp = &hs[d][buf ^ 1][0][0];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int u = 32 * jt + (r & 3) + 8 * (r >> 2) + 4 * h;
             f32x2 rr, zz, nn, gh, hn;
+            f32x2 hprev = {0.f, 0.f};
+            if (t > 0) hprev = *(const f32x2*)(hp + u * GF + 2 * c);
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 rr[e] = sigmoidf_(acc[0][e][r]);
                 zz[e] = sigmoidf_(acc[1][e][r]);
                 gh[e] = acc[2][e][r];
                 nn[e] = tanhf_(fmaf(rr[e], gh[e], gin[r][e]));
-                hn[e] = fmaf(zz[e], hprev[r][e] - nn[e], nn[e]);
-                hprev[r][e] = hn[e];
+                hn[e] = fmaf(zz[e], hprev[e] - nn[e], nn[e]);
             }
             *(f32x2*)(hw + u * GF + 2 * c) = hn;
             const size_t o = ((size_t)(d * H + u) * L + pos) * NP + n0 + 2 * c;
