@@ -68,8 +68,12 @@ __device__ __forceinline__ void sf_load(float* af, const float* tile, int lane) 
 // One wave per SIMD must hide the LDS latency of its own B operand: the read for k-pair kk + LA is issued right before
 // the MFMA of k-pair kk, and the order is pinned (hipcc otherwise sinks every ds_read directly in front of the MFMA that
 // consumes it and the matrix pipe idles ~75 cycles per pair of MFMAs: measured 63 % -> see DESIGN.md).
-template <int KP>
-__device__ __forceinline__ void sf_mm(f32x16& acc, const float* af, const float* S, int rs2) {
+// (NQN > 0 with pf set requests the NQN quads of the NEXT layer's fragments in between the MFMAs instead of as one block
+// in front of the layer, which holds each wave for ~1.2k cycles at 64 B/clk/CU of L1 fill.  Measured: no gain -- the wave
+// stalls on the full memory queue wherever the loads sit, and the extra live ranges spilled; the call sites use NQN = 0.)
+template <int KP, int NQN = 0>
+__device__ __forceinline__ void sf_mm(f32x16& acc, const float* af, const float* S, int rs2, bool pf = false,
+                                      float* fpn = nullptr, const f32x4* pn = nullptr) {
     constexpr int LA = 6;
     float b[KP];
 #if defined(SF_ABL) && (SF_ABL & 1)      // diagnostic: no LDS reads for the B operand (wrong results, timing only)
@@ -88,6 +92,15 @@ __device__ __forceinline__ void sf_mm(f32x16& acc, const float* af, const float*
 #pragma unroll
     for (int kk = 0; kk < KP; ++kk) {
         if (kk + LA < KP && !SF_ABL_NOB) b[kk + LA] = S[(kk + LA) * rs2];
+        if constexpr (NQN > 0) {
+            if (pf) {
+#pragma unroll
+                for (int i = kk * NQN / KP; i < (kk + 1) * NQN / KP; ++i) {
+                    const f32x4 t = pn[i * 64];
+                    fpn[4 * i + 0] = t[0]; fpn[4 * i + 1] = t[1]; fpn[4 * i + 2] = t[2]; fpn[4 * i + 3] = t[3];
+                }
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], b[kk], acc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -107,9 +120,10 @@ __device__ __forceinline__ void sf_guards(float* lds, int buf, int rows, int ls,
 
 // Pointwise conv (+ folded BatchNorm) over one or two sources: dst[m][p] = act(bias[m] + sum_k W[m][k] src[k][p + coff]).
 // NRT row tiles of 32: 4 -> one per wave; 2 -> wave (row tile, column-tile parity); 1 -> waves split the column tiles.
-template <int KP1, int KP2, int NRT>
+template <int KP1, int KP2, int NRT, int NQN = 0>
 __device__ __forceinline__ void sf_pw(const float* af, float* lds, int src1, int ls1, int coff1, int src2, int ls2, int dst,
-                                      int lsd, int P, int M, int row0, bool relu) {
+                                      int lsd, int P, int M, int row0, bool relu, float* fpn = nullptr,
+                                      const float* tile_next = nullptr) {
     const int tid_ = sf_tid();
     const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), h = lane >> 5, c = lane & 31;
     const int rt = NRT == 4 ? wave : (NRT == 2 ? (wave & 1) : 0);
@@ -127,25 +141,34 @@ __device__ __forceinline__ void sf_pw(const float* af, float* lds, int src1, int
         }
     };
     int ct = ct0;
+    bool pf = NQN > 0;                       // the next layer's fragments ride along with this wave's first tile
+    const f32x4* pn = (const f32x4*)tile_next + lane;
     for (; ct < nct; ct += cts) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        sf_mm<KP1>(acc, af, lds + src1 + h * ls1 + 4 + ct * 32 + c + coff1, 2 * ls1);
+        sf_mm<KP1, NQN>(acc, af, lds + src1 + h * ls1 + 4 + ct * 32 + c + coff1, 2 * ls1, pf, fpn, pn);
+        pf = false;
         if constexpr (KP2 > 0) sf_mm<KP2>(acc, af + KP1, lds + src2 + h * ls2 + 4 + ct * 32 + c, 2 * ls2);
         store(acc, ct);
+    }
+    if constexpr (NQN > 0) {
+        if (pf) sf_load<NQN>(fpn, tile_next, lane);      // a wave without a tile in this layer still needs its fragments
     }
 }
 
 // ConvTranspose1d(64 -> 64, k = TAPS, stride S_, padding S_/2) + folded BatchNorm + ReLU.  Output position p = S_ j + e:
 // class e uses the taps with (e + pad - tap) % S_ == 0 at source column j + (e + pad - tap) / S_ -- a dense GEMM per tap.
-template <int TAPS, int S_>
-__device__ __forceinline__ void sf_convT(const float* af, float* lds, int src, int lsi, int dst, int lsd, int Lout) {
+template <int TAPS, int S_, int NQN = 0>
+__device__ __forceinline__ void sf_convT(const float* af, float* lds, int src, int lsi, int dst, int lsd, int Lout,
+                                         float* fpn = nullptr, const float* tile_next = nullptr) {
     const int tid_ = sf_tid();
     const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), h = lane >> 5, c = lane & 31;
     const int rt = wave & 1;
     constexpr int PAD = S_ / 2;
     int ucount = 0;
+    bool pf = NQN > 0;
+    const f32x4* pn = (const f32x4*)tile_next + lane;
 #pragma unroll
     for (int e = 0; e < S_; ++e) {
         const int nj = (Lout - e + S_ - 1) / S_;
@@ -160,7 +183,8 @@ __device__ __forceinline__ void sf_convT(const float* af, float* lds, int src, i
                 constexpr int BIG = 8 * S_;
                 if ((e + PAD - tap + BIG) % S_ == 0) {
                     const int d = (e + PAD - tap + BIG) / S_ - 8;
-                    sf_mm<32>(acc, af + tap * 32, lds + src + h * lsi + 4 + jt * 32 + c + d, 2 * lsi);
+                    sf_mm<32, NQN>(acc, af + tap * 32, lds + src + h * lsi + 4 + jt * 32 + c + d, 2 * lsi, pf, fpn, pn);
+                    pf = false;
                 }
             }
             const int p = S_ * (jt * 32 + c) + e;
@@ -171,6 +195,9 @@ __device__ __forceinline__ void sf_convT(const float* af, float* lds, int src, i
                 if (p < Lout) lds[dst + row * lsd + 4 + p] = v;
             }
         }
+    }
+    if constexpr (NQN > 0) {
+        if (pf) sf_load<NQN>(fpn, tile_next, lane);
     }
 }
 
@@ -329,6 +356,25 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
 #pragma unroll
                     for (int k = 0; k < 5; ++k)
                         xin[ci][k] = ci < Cin ? lds[SF_XB + ci * LSX + 4 + 2 * lo - 1 + k] : 0.f;
+                if (Cin == 4) {
+                    // 20 weights of one output channel = 5 aligned quads (wave-uniform, broadcast reads)
+                    for (int co = 32 * cg; co < 32 * cg + 32; co += 2) {
+                        float v0 = lds[SF_W0 + 1280 + co], v1 = lds[SF_W0 + 1280 + co + 1];
+#pragma unroll
+                        for (int q5 = 0; q5 < 5; ++q5) {
+                            const f32x4 w0 = *(const f32x4*)(lds + SF_W0 + co * 20 + 4 * q5);
+                            const f32x4 w1 = *(const f32x4*)(lds + SF_W0 + (co + 1) * 20 + 4 * q5);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int idx = 4 * q5 + e;                   // = ci * 5 + k
+                                v0 = fmaf(w0[e], xin[idx / 5][idx % 5], v0);
+                                v1 = fmaf(w1[e], xin[idx / 5][idx % 5], v1);
+                            }
+                        }
+                        lds[SF_R0 + co * LSA + 4 + lo] = fmaxf(v0, 0.f);
+                        lds[SF_R0 + (co + 1) * LSA + 4 + lo] = fmaxf(v1, 0.f);
+                    }
+                } else
                 for (int co = 32 * cg; co < 32 * cg + 32; co += 4) {
                     float v[4];
 #pragma unroll
@@ -419,71 +465,59 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
 #endif
         {
             SF_STAMP(7);
-            // recurrence: direction d = tid >> 7; thread u owns row u of W_hh[d] (r | z rows) and one K-half of row
-            // 128 + (u & 63) (the n rows): 96 multiply-adds per thread and step, weights in registers for all 16 steps
+            // recurrence: direction d = tid >> 7 (two waves each); hidden unit j = (tid & 127) >> 1 is owned by the lane
+            // PAIR (2 j, 2 j + 1): lane half kh = tid & 1 holds the K-half [32 kh, 32 kh + 32) of the three W_hh rows of
+            // the unit (r, z, n: 96 registers for all 16 steps), the halves are combined with one cross-lane add (DPP),
+            // both lanes evaluate the gates and the even one writes h: ONE barrier per step, no exchange of W_hh h.
             const int t_ = sf_tid();
-            const int d = t_ >> 7, u = t_ & 127, kh = (u >> 6) * 32;
-            // exporter layout: [direction][24 quads][128 threads][4]: quads 0..15 = row u, 16..23 = this thread's K-half of
-            // row 128 + (u & 63); then b_hh [2][192] -- every load is 16 bytes per lane, consecutive lanes consecutive
-            const f32x4* whh = (const f32x4*)(blob + A.o_whh) + (size_t)d * 24 * 128 + u;
+            const int d = t_ >> 7, j = (t_ & 127) >> 1, kh = t_ & 1;
+            // exporter layout: [direction][24 quads][128 threads][4]: thread (2 j + kh), quad 8 g + i = W_hh[g*64 + j][32 kh +
+            // 4 i .. + 3]; then b_hh [2][192] -- every load is 16 bytes per lane, consecutive lanes consecutive
+            const f32x4* whh = (const f32x4*)(blob + A.o_whh) + (size_t)d * 24 * 128 + (t_ & 127);
             const float* bhh = blob + A.o_whh + 2 * 24 * 128 * 4 + d * 192;
-            float wA[64], wB[32];
-            const int rowB = 128 + (u & 63);
+            float wr[32], wz[32], wn[32];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const f32x4 ta = whh[q * 128];
+            for (int i = 0; i < 8; ++i) {
+                const f32x4 tr = whh[i * 128], tz = whh[(8 + i) * 128], tn = whh[(16 + i) * 128];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) wA[4 * q + e] = ta[e];
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const f32x4 tb = whh[(16 + q) * 128];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) wB[4 * q + e] = tb[e];
+                for (int e = 0; e < 4; ++e) { wr[4 * i + e] = tr[e]; wz[4 * i + e] = tz[e]; wn[4 * i + e] = tn[e]; }
             }
             // opaque copies: the compiler must keep them in registers instead of re-loading them from memory every step
 #pragma unroll
-            for (int k = 0; k < 64; ++k) asm volatile("" : "+v"(wA[k]));
-#pragma unroll
-            for (int k = 0; k < 32; ++k) asm volatile("" : "+v"(wB[k]));
-            const float bA = bhh[u], bB = (u < 64) ? bhh[rowB] : 0.f;
-            float* hs = lds + SF_GRU + d * 64;               // h of this direction
-            float* ghs = lds + SF_GRU + 128 + d * 256;       // [0,128): r | z rows, [128,192) and [192,256): halves of n
-            if (u < 64) hs[u] = 0.f;
+            for (int k = 0; k < 32; ++k) asm volatile("" : "+v"(wr[k]), "+v"(wz[k]), "+v"(wn[k]));
+            const float br = bhh[j], bz = bhh[64 + j], bn = bhh[128 + j];
+            float* hs = lds + SF_GRU + d * 128;              // h of this direction, double-buffered: [2][64]
+            if ((t_ & 127) < 64) hs[t_ & 127] = 0.f;
+            float hme = 0.f;                                 // h_{t-1}[j]
             SF_SYNC();
             SF_STAMP(23);
             for (int st = 0; st < 16; ++st) {
                 const int pos = d ? 15 - st : st;
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-                f32x4 hv[16];
+                const float* hc = hs + (st & 1) * 64 + 32 * kh;
+                const float* gi = lds + SF_R1A + (d * 192 + j) * LSG + 4 + pos;
+                const float gir = gi[0], giz = gi[64 * LSG], gin = gi[128 * LSG];
+                f32x4 hv[8];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) hv[i] = *(const f32x4*)(hs + 4 * i);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    a0 = fmaf(wA[4 * i], hv[i][0], a0); a1 = fmaf(wA[4 * i + 1], hv[i][1], a1);
-                    a2 = fmaf(wA[4 * i + 2], hv[i][2], a2); a3 = fmaf(wA[4 * i + 3], hv[i][3], a3);
-                }
+                for (int i = 0; i < 8; ++i) hv[i] = *(const f32x4*)(hc + 4 * i);
+                float r0 = 0.f, r1 = 0.f, z0 = 0.f, z1 = 0.f, n0_ = 0.f, n1 = 0.f;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    // K-half kh = 0 or 32: hv[i] or hv[8 + i] (a select on registers, no second LDS read)
-                    f32x4 hh;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) hh[e] = kh ? hv[8 + i][e] : hv[i][e];
-                    b0 = fmaf(wB[4 * i], hh[0], b0); b1 = fmaf(wB[4 * i + 1], hh[1], b1);
-                    b2 = fmaf(wB[4 * i + 2], hh[2], b2); b3 = fmaf(wB[4 * i + 3], hh[3], b3);
+                    r0 = fmaf(wr[4 * i], hv[i][0], r0); r1 = fmaf(wr[4 * i + 1], hv[i][1], r1);
+                    r0 = fmaf(wr[4 * i + 2], hv[i][2], r0); r1 = fmaf(wr[4 * i + 3], hv[i][3], r1);
+                    z0 = fmaf(wz[4 * i], hv[i][0], z0); z1 = fmaf(wz[4 * i + 1], hv[i][1], z1);
+                    z0 = fmaf(wz[4 * i + 2], hv[i][2], z0); z1 = fmaf(wz[4 * i + 3], hv[i][3], z1);
+                    n0_ = fmaf(wn[4 * i], hv[i][0], n0_); n1 = fmaf(wn[4 * i + 1], hv[i][1], n1);
+                    n0_ = fmaf(wn[4 * i + 2], hv[i][2], n0_); n1 = fmaf(wn[4 * i + 3], hv[i][3], n1);
                 }
-                ghs[u] = (a0 + a1) + (a2 + a3) + bA;
-                ghs[128 + u] = (b0 + b1) + (b2 + b3) + bB;
-                SF_SYNC();
-                if (u < 64) {
-                    const float* gi = lds + SF_R1A + (d * 192 + u) * LSG + 4 + pos;
-                    const float r = sf_sigmoid(gi[0] + ghs[u]);
-                    const float z = sf_sigmoid(gi[64 * LSG] + ghs[64 + u]);
-                    const float nn = sf_tanh(fmaf(r, ghs[128 + u] + ghs[192 + u], gi[128 * LSG]));
-                    const float hn = (1.f - z) * nn + z * hs[u];
-                    lds[SF_R0 + (d * 64 + u) * LSA + 4 + pos] = hn;
-                    hs[u] = hn;
+                float gr = r0 + r1, gz = z0 + z1, gn = n0_ + n1;
+                gr += __shfl_xor(gr, 1); gz += __shfl_xor(gz, 1); gn += __shfl_xor(gn, 1);      // the other K-half
+                const float r = sf_sigmoid(gir + gr + br);
+                const float z = sf_sigmoid(giz + gz + bz);
+                const float nn = sf_tanh(fmaf(r, gn + bn, gin));
+                hme = (1.f - z) * nn + z * hme;
+                if (kh == 0) {
+                    hs[((st + 1) & 1) * 64 + j] = hme;
+                    lds[SF_R0 + (d * 64 + j) * LSA + 4 + pos] = hme;
                 }
                 SF_SYNC();
                 if (st == 0) SF_STAMP(24);

@@ -80,14 +80,17 @@ def fold(net):
     Wih = np.concatenate([t(g.weight_ih_l0), t(g.weight_ih_l0_reverse)], 0)
     bih = np.concatenate([t(g.bias_ih_l0), t(g.bias_ih_l0_reverse)], 0)
     add(_frag_tiles(Wih, bih))                                                         # o_gi
-    # recurrence weights in the order the kernel's threads read them: [direction][24 quads][128 threads][4]; thread u owns
-    # row u (quads 0..15) and the K-half (u >> 6) of row 128 + (u & 63) (quads 16..23); then b_hh of both directions
+    # recurrence weights in the order the kernel's threads read them: [direction][24 quads][128 threads][4]; thread
+    # t = 2 j + kh owns the K-half [32 kh, 32 kh + 32) of rows j (r), 64 + j (z), 128 + j (n): quad 8 g + i holds
+    # W_hh[64 g + j][32 kh + 4 i .. + 3]; then b_hh of both directions
     whh = []
     for W in (t(g.weight_hh_l0), t(g.weight_hh_l0_reverse)):
-        u = np.arange(128)
-        rows = W[u].reshape(128, 16, 4).transpose(1, 0, 2)                                       # (16, 128, 4)
-        half = np.stack([W[128 + (i & 63), 32 * (i >> 6):32 * (i >> 6) + 32] for i in u])      # (128, 32)
-        whh.append(np.concatenate([rows, half.reshape(128, 8, 4).transpose(1, 0, 2)], 0).reshape(-1))
+        blk = np.zeros((24, 128, 4))
+        for tt in range(128):
+            j, kh = tt >> 1, tt & 1
+            for gg in range(3):
+                blk[8 * gg:8 * gg + 8, tt, :] = W[64 * gg + j, 32 * kh:32 * kh + 32].reshape(8, 4)
+        whh.append(blk.reshape(-1))
     add(np.concatenate(whh + [t(g.bias_hh_l0), t(g.bias_hh_l0_reverse)]))                          # o_whh
     sc, sh = _bn_affine(net.FGRU.conv[1])
     fc = net.FGRU.conv[0]
