@@ -8,7 +8,9 @@
  *     unless named h_*; every call is asynchronous on `stream` (a hipStream_t passed as void*).
  *   - returns 0 on success, a negative TRUNET_E* code otherwise; never throws, never
  *     allocates or frees caller memory, keeps no global mutable state.
- *   - all arithmetic is fp32 ("f32"); BatchNorm statistics are reduced in fp64.
+ *   - all arithmetic is fp32 ("f32"); BatchNorm statistics are reduced in fp64.  The trunet_bf16_* family at the end
+ *     (BASELINE.json configs[2]) stores activations / their gradients as bf16 and multiplies on the bf16 MFMA with fp32
+ *     accumulation; everything else about it (statistics, coefficients, weight gradients) stays fp32.
  *
  * Internal activation layout ("frames-last"): a tensor of C channels x L positions for N frames
  * is stored as float[C][L][NP] with NP = N rounded up to a multiple of 128 (the host engine pads to 256, the widest
@@ -345,6 +347,69 @@ int trunet_stream_fwd(const float* x, float* y, const float* blob, const int32_t
  * highpass_biquad -> lfilter(clamp=True), the calls of dataset.py:123-125).  noisy must not alias noise. */
 int trunet_augment_mix(const float* noise, const float* clean, const float* params, float* noisy, float* noise_out, int B,
                        int L, void* stream);
+
+/* ======================================================================================================================
+ * bf16 storage / bf16 MFMA family (BASELINE.json configs[2]; build extension: the reference has no reduced-precision path,
+ * SURVEY 8d).  Activations and their gradients are stored as bf16 in the "octet" layout
+ *     uint16 t[C/8][L][NP][8]      element (c, l, n) at (((c/8)*L + l)*NP + n)*8 + c%8
+ * (channels padded to a multiple of 8 with zeros; NP a multiple of 64): a v_mfma_f32_32x32x16_bf16 B fragment -- 8
+ * consecutive channels of one frame -- is ONE 16-byte load per lane, and taps / strides / pad / crop / cat stay whole-row
+ * offsets as in the fp32 layout.  Accumulation, BatchNorm statistics (taken from the ROUNDED stored values, so forward and
+ * backward see the same tensor), coefficients, weight gradients, master weights: fp32.
+ * ====================================================================================================================== */
+typedef struct {
+    const void* src0;   /* bf16 octet tensor [ceil(nchan/8)][L][NP][8] */
+    const void* src1;   /* second tensor for TRUNET_PRO_BNBWD */
+    const float* c0; const float* c1; const float* c2;   /* per-channel coefficients [nchan] */
+    int32_t nchan, L, pos_mul, pos_off, pos_div, mode;
+    int32_t kstep0;     /* trunet_bf16_gemm: first 16-channel k-step of this segment in the packed weight image */
+    int32_t woff;       /* trunet_bf16_wgrad: weight offset of this segment (as trunet_seg.woff) */
+} trunet_bseg;
+/* out[m][p + out_pos_off][n] = epi( sum_seg sum_c W(m, seg, c) * pro_seg(src_seg[c][q_seg(p)][n]) ), all tensors in the octet
+ * layout, same prologue / epilogue flags as trunet_conv_gemm (network.py:13,28,50,64,67,83,86,106,109 and their data
+ * gradients).  wfrag: the weight as packed by trunet_bf16_pack_weight ([row tile][k-step][64 lanes][8 bf16], MFMA A-fragment
+ * order).  M <= 128.  Statistics partial rows: partials[trunet_bf16_gemm_nparts()][M_stat][2] (zero-filled by the call). */
+typedef struct {
+    int32_t NP, N, P, p_begin, M, out_L, out_pos_off, nseg, epi, M_stat, nks_total, _pad;
+    void* out; const void* wfrag; const float* bias; const void* zmask;
+    const float* e0; const float* e1; const float* e2; float* partials;
+    trunet_bseg seg[TRUNET_MAX_SEG];
+} trunet_bgemm_args;
+int trunet_bf16_gemm_nparts(void);
+int trunet_bf16_gemm(const trunet_bgemm_args* h_args, void* stream);
+/* pack an fp32 weight into the A-fragment image: A(m, k) = W[(m + w_m_off)*ldw_m + c*ldw_c + h_seg_woff[s]] for segments of
+ * h_seg_nchan[s] channels, each padded to whole k-steps of 16:
+ * wfrag[((rt*nks_total + ks)*64 + lane)*8 + j] = A(32 rt + lane%32, 16 ks + 8 (lane/32) + j); returns nks_total (> 0) */
+int trunet_bf16_pack_weight(const float* W, void* wfrag, int M, int ldw_m, int ldw_c, int w_m_off, int nseg,
+                            const int32_t* h_seg_nchan, const int32_t* h_seg_woff, void* stream);
+/* weight gradient of the same implicit GEMM from octet tensors: dW[(m+w_m_off)*ldw_m + c*ldw_c + woff_s] = sum_{p,n<N}
+ * dz[m][p + a_pos_off][n] pro_s(src_s[c][q_s(p)][n]), dz = a0 (PRO_NONE) or ac0 a0 + ac1 a1 + ac2; fp32 partial images / bias
+ * partial rows exactly as trunet_conv_wgrad (trunet_conv_wgrad_nparts() images, image stride w_numel).  M <= 128, at most 40
+ * source octets over all segments.  A step is (position, 64 frames): every operand row is read from HBM once, transformed and
+ * written to LDS as [octet][frame][8 channels]; the frame axis becomes the MFMA K axis through ds_read_b64_tr_b16. */
+typedef struct {
+    int32_t NP, N, P, p_begin, M, a_L, a_pos_off, a_mode, ldw_m, ldw_c, w_m_off, nseg, w_numel, b_stride, b_off, _pad;
+    const void* a0; const void* a1; const float* ac0; const float* ac1; const float* ac2;
+    float* w_partials; float* b_partials;
+    trunet_bseg seg[TRUNET_MAX_SEG];
+} trunet_bwgrad_args;
+int trunet_bf16_wgrad(const trunet_bwgrad_args* h_args, void* stream);
+/* depthwise conv in the octet layout (network.py:33-38): BN+ReLU prologue on the input, raw bf16 output, fp32 statistics
+ * partials[trunet_bf16_dw_nparts(NP, rows)][C][2] (rows = Lout forward, Lin backward); backward: dz = ca dy + cb z + cc, masked
+ * data gradient of the input (+ its BatchNorm-backward sums), fp32 partial images w_partials[nparts][C][K],
+ * b_partials[nparts][C].  A thread owns (octet, frame) and walks positions with a sliding register window: every tensor is
+ * read once.  (K, S) in {(3,1), (5,2), (3,2)}; C a multiple of 8. */
+int trunet_bf16_dw_nparts(int NP, int rows);
+int trunet_bf16_dwconv_fwd(const void* zin, const float* s_in, const float* t_in, const float* w, const float* b, void* zout,
+                           float* partials, int C, int K, int S, int Lin, int Lout, int NP, int N, void* stream);
+int trunet_bf16_dwconv_bwd(const void* dy, const void* z, const float* ca, const float* cb, const float* cc, const void* zin,
+                           const float* s_in, const float* t_in, const float* mean_in, const float* w, void* dy_in,
+                           float* partials_in, float* w_partials, float* b_partials, int C, int K, int S, int Lin, int Lout,
+                           int NP, int N, void* stream);
+/* layout changes: frames-last fp32 [C][L][NP] <-> octet bf16 (network input / output and the fp32 bottleneck of the bf16
+ * path: FGRU); channels C..8*ceil(C/8)-1 of the octet tensor are written as zeros */
+int trunet_bf16_from_frames_last(const float* x, void* y_oct, int C, int L, int NP, void* stream);
+int trunet_bf16_to_frames_last(const void* x_oct, float* y, int C, int L, int NP, void* stream);
 
 /* calibration: sustained fp32 MFMA rate at the device's operating clock (out: blocks*256 floats) */
 int trunet_debug_mfma_peak(float* out, int blocks, int iters, void* stream);

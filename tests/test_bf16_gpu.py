@@ -1,0 +1,564 @@
+"""GPU: the bf16 storage / bf16 MFMA family (BASELINE.json configs[2], a build extension -- SURVEY 8d: the reference has no
+reduced-precision path, so the gate is against fp32 with a stated looser tolerance).
+
+Unit level: every trunet_bf16_* kernel against a torch restatement of the SAME arithmetic (operands rounded to bf16
+where the kernel rounds them, fp32/fp64 accumulation), so the bound is the final bf16 rounding of the stored value
+(2^-8 relative) resp. fp32 accumulation error for the fp32 outputs.  Network level: forward within 1e-2 relative of the
+fp32 HIP path, loss within 1 %, gradients close in relative L2."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _rb(x):
+    return x.bfloat16().float()
+
+
+def to_oct(x):
+    """fp32 [C][L][NP] -> bf16 octets [C/8][L][NP][8] (channels zero-padded to a multiple of 8)"""
+    C, Ln, NP = x.shape
+    C8 = (C + 7) // 8 * 8
+    if C8 != C:
+        x = torch.cat([x, torch.zeros(C8 - C, Ln, NP, device=x.device)], 0)
+    return x.view(C8 // 8, 8, Ln, NP).permute(0, 2, 3, 1).contiguous().bfloat16()
+
+
+def from_oct(t, C):
+    o, Ln, NP, _ = t.shape
+    return t.float().permute(0, 3, 1, 2).reshape(o * 8, Ln, NP)[:C].contiguous()
+
+
+def _gen(seed):
+    g = torch.Generator(device=DEV)
+    g.manual_seed(seed)
+    return lambda *s: torch.randn(*s, generator=g, device=DEV)
+
+
+def _seg_q(p, mul, off, div, Ls):
+    qn = p * mul + off
+    if qn < 0 or qn % div or qn // div >= Ls:
+        return None
+    return qn // div
+
+
+def _run_gemm(N, P, M, segs, W, ldw_m, ldw_c, w_m_off=0, bias=None, relu=False, mask=None, accum=None, stats=False,
+              p_begin=0, out_L=None, out_pos_off=0):
+    """segs: list of dict(x=fp32 [C][L][NP] (bf16-representable), x1=..., mode, c0, c1, c2, pos_mul, pos_off, pos_div, woff)
+    returns (out fp32 [M][out_L][NP] as stored, stats or None) from the kernel and from the torch restatement."""
+    from tinyrecurrentunet_amd import _lib as L
+    from tinyrecurrentunet_amd._lib import (EPI_ACCUM, EPI_BIAS, EPI_MASK, EPI_RELU, EPI_STATS, PRO_BNBWD, PRO_BNRELU,
+                                            BGemmArgs, check, ptr, ptr16)
+    from tinyrecurrentunet_amd.engine_bf16 import bseg
+    import ctypes as C
+    lib, st = L.lib(), L.stream()
+    NP = segs[0]["x"].shape[2]
+    out_L = out_L or P
+    keep = []
+    bs = []
+    for s in segs:
+        t0 = to_oct(s["x"])
+        t1 = to_oct(s["x1"]) if s.get("x1") is not None else None
+        keep += [t0, t1]
+        bs.append(bseg(t0, s["x"].shape[0], s["x"].shape[1], s.get("pos_mul", 1), s.get("pos_off", 0), s.get("pos_div", 1),
+                       s.get("woff", 0), s.get("mode", 0), src1=t1, c0=s.get("c0"), c1=s.get("c1"), c2=s.get("c2")))
+    nseg = len(bs)
+    nks = sum(((b.nchan + 7) // 8 + 1) // 2 for b in bs)
+    wfrag = torch.empty(((M + 31) // 32) * nks * 64 * 8, device=DEV, dtype=torch.bfloat16)
+    rc = lib.trunet_bf16_pack_weight(ptr(W), ptr16(wfrag), M, ldw_m, ldw_c, w_m_off, nseg,
+                                     (C.c_int32 * nseg)(*[b.nchan for b in bs]), (C.c_int32 * nseg)(*[b.woff for b in bs]), st)
+    assert rc == nks
+    a = BGemmArgs()
+    a.NP, a.N, a.P, a.p_begin, a.M, a.out_L, a.out_pos_off, a.nseg, a.nks_total = NP, N, P, p_begin, M, out_L, out_pos_off, nseg, nks
+    k0 = 0
+    for i, b in enumerate(bs):
+        b.kstep0 = k0
+        k0 += ((b.nchan + 7) // 8 + 1) // 2
+        a.seg[i] = b
+    out0 = accum if accum is not None else torch.zeros(M, out_L, NP, device=DEV)
+    out = to_oct(out0)
+    a.out, a.wfrag = ptr16(out), ptr16(wfrag)
+    epi = 0
+    if bias is not None:
+        epi |= EPI_BIAS
+        a.bias = ptr(bias)
+    if relu:
+        epi |= EPI_RELU
+    if accum is not None:
+        epi |= EPI_ACCUM
+    zm = None
+    if mask is not None:
+        epi |= EPI_MASK
+        zm = to_oct(mask["z"])
+        a.zmask, a.e0, a.e1, a.e2 = ptr16(zm), ptr(mask["e0"]), ptr(mask["e1"]), ptr(mask["e2"])
+    part = None
+    if stats:
+        epi |= EPI_STATS
+        nparts = lib.trunet_bf16_gemm_nparts()
+        part = torch.empty(nparts * M * 2, device=DEV)
+        a.partials, a.M_stat = ptr(part), M
+    a.epi = epi
+    check(lib.trunet_bf16_gemm(a, st), "bf16_gemm")
+    torch.cuda.synchronize()
+    got = from_oct(out, M)
+    got_stats = part.view(-1, M, 2).double().sum(0) if stats else None
+
+    # ---- torch restatement
+    ref = torch.zeros(M, out_L, NP, device=DEV, dtype=torch.float64)
+    if accum is not None:
+        ref += _rb(accum).double()
+    touched = torch.zeros(out_L, dtype=torch.bool)
+    for p in range(p_begin, p_begin + P):
+        acc = torch.zeros(M, NP, device=DEV, dtype=torch.float64)
+        for s in segs:
+            x = s["x"]
+            Cs, Ls = x.shape[0], x.shape[1]
+            q = _seg_q(p, s.get("pos_mul", 1), s.get("pos_off", 0), s.get("pos_div", 1), Ls)
+            if q is None:
+                continue
+            v = x[:, q]
+            mode = s.get("mode", 0)
+            if mode == PRO_BNRELU:
+                v = torch.relu(s["c0"][:, None] * v + s["c1"][:, None])
+            elif mode == PRO_BNBWD:
+                v = s["c0"][:, None] * v + s["c1"][:, None] * s["x1"][:, q] + s["c2"][:, None]
+            v = _rb(v).double()
+            idx = (torch.arange(M, device=DEV)[:, None] + w_m_off) * ldw_m + torch.arange(Cs, device=DEV)[None, :] * ldw_c \
+                + s.get("woff", 0)
+            A = _rb(W.reshape(-1)[idx]).double()
+            acc += A @ v
+        o = acc
+        if bias is not None:
+            o = o + bias[:, None].double()
+        o = o + ref[:, p + out_pos_off]
+        if mask is not None:
+            zz = mask["z"][:, p + out_pos_off]
+            o = torch.where((mask["e0"][:, None] * zz + mask["e1"][:, None]) > 0, o, torch.zeros_like(o))
+        if relu:
+            o = torch.relu(o)
+        ref[:, p + out_pos_off] = o
+        touched[p + out_pos_off] = True
+    ref_stats = None
+    if stats:
+        r = _rb(ref.float()).double()[:, touched][:, :, :N]
+        if mask is not None:
+            zz = mask["z"][:, touched][:, :, :N].double() - mask["e2"][:, None, None].double()
+            ref_stats = torch.stack([r.sum((1, 2)), (r * zz).sum((1, 2))], 1)
+        else:
+            ref_stats = torch.stack([r.sum((1, 2)), (r * r).sum((1, 2))], 1)
+    return got, ref.float(), touched, got_stats, ref_stats
+
+
+def _close_bf16(got, ref, what):
+    err = (got - ref).abs()
+    tol = 2.0 ** -7 * ref.abs() + 1e-2 * ref.abs().mean() + 1e-6
+    bad = (err > tol).float().mean().item()
+    assert bad < 1e-4, "%s: %.2e of the elements off by more than one bf16 ulp (max err %.3e)" % (what, bad, err.max().item())
+
+
+def _stats_close(got, ref, n, what):
+    # the kernel's statistics are those of ITS stored values; one ulp flips of individual elements move a sum by
+    # ~2^-8 * |x| / sqrt(count)
+    scale = ref.abs().max().item() + 1e-6
+    assert (got - ref).abs().max().item() < 2e-3 * scale + 1e-3, "%s: %s vs %s" % (what, got[:4], ref[:4])
+
+
+def test_bf16_gemm_pointwise_two_sources_stats():
+    """decoder pointwise conv over [x1 (shifted by F.pad) | skip] with BN+ReLU prologues, bias, statistics"""
+    rnd = _gen(1)
+    N, NP, P, M = 300, 512, 9, 64
+    x1, x2 = _rb(rnd(64, 8, NP)), _rb(rnd(128, 9, NP))
+    W = rnd(M, 192, 1) * 0.1
+    bias = rnd(M) * 0.1
+    segs = [dict(x=x1, mode=1, c0=rnd(64) * 0.3 + 1, c1=rnd(64) * 0.2, pos_off=-1, woff=0),
+            dict(x=x2, mode=1, c0=rnd(128) * 0.3 + 1, c1=rnd(128) * 0.2, woff=64)]
+    got, ref, touched, gs, rs = _run_gemm(N, P, M, segs, W, 192, 1, bias=bias, stats=True)
+    _close_bf16(got, ref, "pw two sources")
+    _stats_close(gs, rs, N * P, "pw two sources statistics")
+
+
+def test_bf16_gemm_transposed_conv_taps_m128_and_m8():
+    rnd = _gen(2)
+    N, NP = 200, 256
+    # ConvTranspose1d(64 -> 64, k=5, s=2, pad=1): Lin 7 -> Lout 15
+    x = _rb(rnd(64, 7, NP))
+    W = rnd(64, 64, 5) * 0.1          # [ci][co][k]
+    c0, c1 = rnd(64) * 0.3 + 1, rnd(64) * 0.2
+    segs = [dict(x=x, mode=1, c0=c0, c1=c1, pos_off=1 - kk, pos_div=2, woff=kk) for kk in range(5)]
+    got, ref, _, gs, rs = _run_gemm(N, 15, 64, segs, W, 5, 64 * 5, bias=rnd(64) * 0.1, stats=True)
+    _close_bf16(got, ref, "convT k5 s2")
+    _stats_close(gs, rs, N * 15, "convT statistics")
+    # 128 rows (two waves share a tile), plain source, ReLU epilogue
+    x = _rb(rnd(64, 6, NP))
+    W = rnd(128, 64, 1) * 0.1
+    got, ref, _, _, _ = _run_gemm(N, 6, 128, [dict(x=x)], W, 64, 1, bias=rnd(128) * 0.1, relu=True)
+    _close_bf16(got, ref, "M=128 relu")
+    # 8 rows (decoder.5): 128 -> 8 and the 8 -> 8 transposed conv
+    x = _rb(rnd(128, 6, NP))
+    W = rnd(8, 128, 1) * 0.1
+    got, ref, _, _, _ = _run_gemm(N, 6, 8, [dict(x=x, mode=1, c0=rnd(128) * 0.3 + 1, c1=rnd(128) * 0.2)], W, 128, 1,
+                                  bias=rnd(8) * 0.1)
+    _close_bf16(got, ref, "M=8")
+    # first conv: 4 channels (padded octet), k=5 s=2 pad=1: 257 -> 128 positions (take 21 -> 10)
+    x = _rb(rnd(4, 21, NP))
+    W = rnd(64, 4, 5) * 0.3
+    segs = [dict(x=x, pos_mul=2, pos_off=kk - 1, woff=kk) for kk in range(5)]
+    got, ref, _, _, _ = _run_gemm(N, 10, 64, segs, W, 20, 5, bias=rnd(64) * 0.1, relu=True)
+    _close_bf16(got, ref, "first conv")
+
+
+def test_bf16_gemm_data_gradient_bnbwd_mask_accum_stats():
+    """data gradient of a pointwise conv: BatchNorm-backward prologue on (dy, z), transposed weight, output window
+    shifted by the F.pad offset, ReLU mask of the source, accumulation onto the skip gradient, BN-backward statistics"""
+    rnd = _gen(3)
+    N, NP, P, M = 300, 512, 9, 64
+    dy, z = _rb(rnd(M, P, NP)), _rb(rnd(M, P, NP))
+    W = rnd(M, 192, 1) * 0.1
+    seg = dict(x=dy, x1=z, mode=2, c0=rnd(M) * 0.5 + 1, c1=rnd(M) * 0.1, c2=rnd(M) * 0.01)
+    zsrc = _rb(rnd(128, 9, NP))
+    mask = dict(z=zsrc, e0=rnd(128) * 0.3 + 1, e1=rnd(128) * 0.2, e2=rnd(128) * 0.1)
+    prev = _rb(rnd(128, 9, NP))
+    got, ref, touched, gs, rs = _run_gemm(N, P, 128, [seg], W, 1, 192, w_m_off=64, mask=mask, accum=prev, stats=True)
+    _close_bf16(got, ref, "dgrad skip")
+    _stats_close(gs, rs, N * P, "dgrad statistics")
+    # the x1 source: 8 positions, shifted by one (left = 1): p in [1, 9)
+    zsrc = _rb(rnd(64, 8, NP))
+    mask = dict(z=zsrc, e0=rnd(64) * 0.3 + 1, e1=rnd(64) * 0.2, e2=rnd(64) * 0.1)
+    got, ref, touched, gs, rs = _run_gemm(N, 8, 64, [seg], W, 1, 192, w_m_off=0, mask=mask, stats=True, p_begin=1, out_L=8,
+                                          out_pos_off=-1)
+    assert touched.all()
+    _close_bf16(got, ref, "dgrad x1")
+    _stats_close(gs, rs, N * 8, "dgrad x1 statistics")
+
+
+def _run_wgrad(N, P, M, dz, z, co, segs, Wshape, ldw_m, ldw_c):
+    from tinyrecurrentunet_amd import _lib as L
+    from tinyrecurrentunet_amd._lib import PRO_BNBWD, PRO_BNRELU, PRO_NONE, BWgradArgs, check, ptr, ptr16
+    from tinyrecurrentunet_amd.engine_bf16 import bseg
+    lib, st = L.lib(), L.stream()
+    NP = dz.shape[2]
+    numel = 1
+    for d in Wshape:
+        numel *= d
+    npw = lib.trunet_conv_wgrad_nparts()
+    a = BWgradArgs()
+    a.NP, a.N, a.P, a.p_begin, a.M, a.a_L, a.a_pos_off = NP, N, P, 0, M, P, 0
+    a.ldw_m, a.ldw_c, a.w_m_off, a.nseg, a.w_numel = ldw_m, ldw_c, 0, len(segs), numel
+    keep = []
+    for i, s in enumerate(segs):
+        t0 = to_oct(s["x"])
+        keep.append(t0)
+        a.seg[i] = bseg(t0, s["x"].shape[0], s["x"].shape[1], s.get("pos_mul", 1), s.get("pos_off", 0), s.get("pos_div", 1),
+                        s.get("woff", 0), s.get("mode", 0), c0=s.get("c0"), c1=s.get("c1"))
+    d16 = to_oct(dz)
+    a.a0 = ptr16(d16)
+    if z is not None:
+        z16 = to_oct(z)
+        a.a_mode, a.a1, a.ac0, a.ac1, a.ac2 = PRO_BNBWD, ptr16(z16), ptr(co[0]), ptr(co[1]), ptr(co[2])
+    else:
+        a.a_mode = PRO_NONE
+    wp = torch.zeros(npw * numel, device=DEV)
+    bp = torch.zeros(npw * M, device=DEV)
+    a.w_partials, a.b_partials, a.b_stride, a.b_off = ptr(wp), ptr(bp), M, 0
+    check(lib.trunet_bf16_wgrad(a, st), "bf16_wgrad")
+    torch.cuda.synchronize()
+    gw = wp.view(npw, numel).double().sum(0)
+    gb = bp.view(npw, M).double().sum(0)
+    # ---- restatement
+    dzz = dz if z is None else co[0][:, None, None] * dz + co[1][:, None, None] * z + co[2][:, None, None]
+    dzz = dzz.clone()
+    dzz[:, :, N:] = 0
+    rb_ = dzz.double().sum((1, 2))
+    dzr = _rb(dzz).double()
+    rw = torch.zeros(numel, device=DEV, dtype=torch.float64)
+    for s in segs:
+        x = s["x"]
+        Cs, Ls = x.shape[0], x.shape[1]
+        v = x
+        if s.get("mode", 0) == PRO_BNRELU:
+            v = torch.relu(s["c0"][:, None, None] * x + s["c1"][:, None, None])
+        v = _rb(v).double()
+        g = torch.zeros(M, Cs, device=DEV, dtype=torch.float64)
+        for p in range(P):
+            q = _seg_q(p, s.get("pos_mul", 1), s.get("pos_off", 0), s.get("pos_div", 1), Ls)
+            if q is not None:
+                g += dzr[:, p] @ v[:, q].T
+        idx = torch.arange(M, device=DEV)[:, None] * ldw_m + torch.arange(Cs, device=DEV)[None, :] * ldw_c + s.get("woff", 0)
+        rw[idx.reshape(-1)] += g.reshape(-1)
+    return gw, rw, gb, rb_
+
+
+def _l2(a, b):
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def test_bf16_wgrad_shapes_of_the_backward():
+    rnd = _gen(4)
+    N, NP = 300, 512
+    co = lambda M: (rnd(M) * 0.5 + 1, rnd(M) * 0.1, rnd(M) * 0.01)
+    # encoder pointwise 128 <- 128 behind a BatchNorm
+    M, P = 128, 6
+    dz, z = _rb(rnd(M, P, NP)), _rb(rnd(M, P, NP))
+    x = _rb(rnd(128, P, NP))
+    gw, rw, gb, rb_ = _run_wgrad(N, P, M, dz, z, co(M), [dict(x=x, mode=1, c0=rnd(128) * 0.3 + 1, c1=rnd(128) * 0.2)],
+                                 (M, 128, 1), 128, 1)
+    assert _l2(gw, rw) < 3e-4 and _l2(gb, rb_) < 2e-5, (_l2(gw, rw), _l2(gb, rb_))
+    # decoder pointwise 64 <- [64 shifted | 128]
+    M, P = 64, 9
+    dz, z = _rb(rnd(M, P, NP)), _rb(rnd(M, P, NP))
+    segs = [dict(x=_rb(rnd(64, 8, NP)), mode=1, c0=rnd(64) * 0.3 + 1, c1=rnd(64) * 0.2, pos_off=-1, woff=0),
+            dict(x=_rb(rnd(128, 9, NP)), mode=1, c0=rnd(128) * 0.3 + 1, c1=rnd(128) * 0.2, woff=64)]
+    gw, rw, gb, rb_ = _run_wgrad(N, P, M, dz, z, co(M), segs, (M, 192, 1), 192, 1)
+    assert _l2(gw, rw) < 3e-4 and _l2(gb, rb_) < 2e-5, (_l2(gw, rw), _l2(gb, rb_))
+    # transposed conv 64 -> 64, k=5 s=2 pad=1: weight [ci][co][k], dz over 15 output positions, source 7 positions
+    M, P = 64, 15
+    dz, z = _rb(rnd(M, P, NP)), _rb(rnd(M, P, NP))
+    x = _rb(rnd(64, 7, NP))
+    c0, c1 = rnd(64) * 0.3 + 1, rnd(64) * 0.2
+    segs = [dict(x=x, mode=1, c0=c0, c1=c1, pos_off=1 - kk, pos_div=2, woff=kk) for kk in range(5)]
+    gw, rw, gb, rb_ = _run_wgrad(N, P, M, dz, z, co(M), segs, (64, 64, 5), 5, 64 * 5)
+    assert _l2(gw, rw) < 3e-4 and _l2(gb, rb_) < 2e-5, (_l2(gw, rw), _l2(gb, rb_))
+    # thin layers: 8 <- [64 | 64] (decoder.5 pointwise), 8 -> 8 transposed conv without BatchNorm, first conv 64 <- 4 x 5 taps
+    M, P = 8, 6
+    dz, z = _rb(rnd(M, P, NP)), _rb(rnd(M, P, NP))
+    segs = [dict(x=_rb(rnd(64, 6, NP)), mode=1, c0=rnd(64) * 0.3 + 1, c1=rnd(64) * 0.2, woff=0),
+            dict(x=_rb(rnd(64, 6, NP)), woff=64)]
+    gw, rw, gb, rb_ = _run_wgrad(N, P, M, dz, z, co(M), segs, (M, 128, 1), 128, 1)
+    assert _l2(gw, rw) < 3e-4 and _l2(gb, rb_) < 2e-5, (_l2(gw, rw), _l2(gb, rb_))
+    M, P = 8, 15
+    dz = _rb(rnd(M, P, NP))
+    x = _rb(rnd(8, 7, NP))
+    segs = [dict(x=x, mode=1, c0=rnd(8) * 0.3 + 1, c1=rnd(8) * 0.2, pos_off=1 - kk, pos_div=2, woff=kk) for kk in range(5)]
+    for s in segs[1:]:
+        s["c0"], s["c1"] = segs[0]["c0"], segs[0]["c1"]
+    gw, rw, gb, rb_ = _run_wgrad(N, P, M, dz, None, None, segs, (8, 8, 5), 5, 8 * 5)
+    assert _l2(gw, rw) < 3e-4 and _l2(gb, rb_) < 2e-5, (_l2(gw, rw), _l2(gb, rb_))
+    M, P = 64, 10
+    dz = _rb(rnd(M, P, NP))
+    x = _rb(rnd(4, 21, NP))
+    segs = [dict(x=x, pos_mul=2, pos_off=kk - 1, woff=kk) for kk in range(5)]
+    gw, rw, gb, rb_ = _run_wgrad(N, P, M, dz, None, None, segs, (64, 4, 5), 20, 5)
+    assert _l2(gw, rw) < 3e-4 and _l2(gb, rb_) < 2e-5, (_l2(gw, rw), _l2(gb, rb_))
+
+
+@pytest.mark.parametrize("K,S,Lin", [(3, 1, 12), (5, 2, 21), (3, 2, 16), (5, 2, 64), (3, 1, 33)])
+def test_bf16_depthwise_forward_backward(K, S, Lin):
+    from tinyrecurrentunet_amd import _lib as L
+    from tinyrecurrentunet_amd._lib import check, ptr, ptr16
+    import torch.nn.functional as F
+    lib, st = L.lib(), L.stream()
+    rnd = _gen(10 * K + S)
+    N, NP, Cn = 300, 512, 16
+    Lout = (Lin + 2 * (K // 2) - K) // S + 1
+    zin = _rb(rnd(Cn, Lin, NP))
+    sc, sh, mean = rnd(Cn) * 0.3 + 1, rnd(Cn) * 0.2, rnd(Cn) * 0.1
+    wgt, b = rnd(Cn, 1, K) * 0.5, rnd(Cn) * 0.1
+    zin16 = to_oct(zin)
+    zout16 = torch.empty((Cn // 8, Lout, NP, 8), device=DEV, dtype=torch.bfloat16)
+    nparts = lib.trunet_bf16_dw_nparts(NP, Lout)
+    part = torch.zeros(nparts * Cn * 2, device=DEV)
+    check(lib.trunet_bf16_dwconv_fwd(ptr16(zin16), ptr(sc), ptr(sh), ptr(wgt), ptr(b), ptr16(zout16), ptr(part), Cn, K, S, Lin,
+                                     Lout, NP, N, st), "fwd")
+    torch.cuda.synchronize()
+    act = torch.relu(sc[:, None, None] * zin + sh[:, None, None])                       # [C][L][NP]
+    ref = F.conv1d(act.permute(2, 0, 1).double(), wgt.double(), b.double(), stride=S, padding=K // 2, groups=Cn)
+    ref = ref.permute(1, 2, 0).float()                                                  # [C][Lout][NP]
+    got = from_oct(zout16, Cn)
+    _close_bf16(got, ref, "dw forward")
+    r = _rb(ref)[:, :, :N].double()
+    st_ref = torch.stack([r.sum((1, 2)), (r * r).sum((1, 2))], 1)
+    _stats_close(part.view(nparts, Cn, 2).double().sum(0), st_ref, N * Lout, "dw statistics")
+
+    # ---- backward
+    dy, z = _rb(rnd(Cn, Lout, NP)), _rb(rnd(Cn, Lout, NP))
+    ca, cb, cc = rnd(Cn) * 0.5 + 1, rnd(Cn) * 0.1, rnd(Cn) * 0.01
+    dy16, z16 = to_oct(dy), to_oct(z)
+    din16 = torch.empty((Cn // 8, Lin, NP, 8), device=DEV, dtype=torch.bfloat16)
+    nparts = lib.trunet_bf16_dw_nparts(NP, Lin)
+    part = torch.zeros(nparts * Cn * 2, device=DEV)
+    wp = torch.zeros(nparts * Cn * K, device=DEV)
+    bp = torch.zeros(nparts * Cn, device=DEV)
+    check(lib.trunet_bf16_dwconv_bwd(ptr16(dy16), ptr16(z16), ptr(ca), ptr(cb), ptr(cc), ptr16(zin16), ptr(sc), ptr(sh),
+                                     ptr(mean), ptr(wgt), ptr16(din16), ptr(part), ptr(wp), ptr(bp), Cn, K, S, Lin, Lout, NP,
+                                     N, st), "bwd")
+    torch.cuda.synchronize()
+    dz = (ca[:, None, None] * dy + cb[:, None, None] * z + cc[:, None, None]).double()
+    dz[:, :, N:] = 0
+    dzn = dz.permute(2, 0, 1)                                                           # [NP][C][Lout]
+    actn = act.permute(2, 0, 1).double().requires_grad_(True)
+    wd = wgt.double().requires_grad_(True)
+    bd = b.double().requires_grad_(True)
+    y = F.conv1d(actn, wd, bd, stride=S, padding=K // 2, groups=Cn)
+    y.backward(dzn)
+    gin = (actn.grad.permute(1, 2, 0) * (act > 0)).float()
+    got = from_oct(din16, Cn)
+    _close_bf16(got, gin, "dw data gradient")
+    assert _l2(wp.view(nparts, -1).double().sum(0), wd.grad.reshape(-1)) < 3e-4
+    assert _l2(bp.view(nparts, -1).double().sum(0), bd.grad) < 2e-5
+    r = _rb(gin)[:, :, :N].double()
+    st_ref = torch.stack([r.sum((1, 2)), (r * (zin[:, :, :N].double() - mean[:, None, None].double())).sum((1, 2))], 1)
+    _stats_close(part.view(nparts, Cn, 2).double().sum(0), st_ref, N * Lin, "dw backward statistics")
+
+
+def test_bf16_layout_round_trip():
+    from tinyrecurrentunet_amd import _lib as L
+    from tinyrecurrentunet_amd._lib import check, ptr, ptr16
+    lib, st = L.lib(), L.stream()
+    rnd = _gen(7)
+    for Cn in (4, 8, 128):
+        x = rnd(Cn, 5, 256)
+        y16 = torch.empty(((Cn + 7) // 8, 5, 256, 8), device=DEV, dtype=torch.bfloat16)
+        check(lib.trunet_bf16_from_frames_last(ptr(x), ptr16(y16), Cn, 5, 256, st), "from")
+        assert torch.equal(y16, to_oct(x))
+        back = torch.empty_like(x)
+        check(lib.trunet_bf16_to_frames_last(ptr16(y16), ptr(back), Cn, 5, 256, st), "to")
+        assert torch.equal(back, _rb(x))
+
+
+def _pair(cin, seed=0):
+    from tinyrecurrentunet_amd.network import TRUNet
+    torch.manual_seed(seed)
+    a = TRUNet(input_size=cin).cuda().train()
+    b = TRUNet(input_size=cin, precision="bf16").cuda().train()
+    b.load_state_dict(a.state_dict())
+    return a, b
+
+
+def test_bf16_backward_matches_fp32_backward_on_the_same_forward_state():
+    """The whole-network gradient reacts chaotically to bf16-sized perturbations of the FORWARD (ReLU masks flip: see
+    the next test), so the wiring of the bf16 backward is pinned where it is well conditioned: given the forward state,
+    backward is a LINEAR map of the output cotangent.  The bf16 forward's saved tensors are converted to fp32 exactly and
+    handed to the fp32 engine's backward (fused fp32 kernels, already pinned against the reference); the bf16 backward on
+    the same state may differ only by the bf16 rounding of the activation gradients it stores and multiplies (2^-9 each,
+    ~40 stages deep at the first layer: measured 1e-3 at decoder.5 growing to 3e-2 at encoder.0; gate 5e-2)."""
+    from tinyrecurrentunet_amd import _lib as L
+    from tinyrecurrentunet_amd._lib import check, ptr, ptr16
+    from tinyrecurrentunet_amd.engine import Act, TRUNetEngine
+    from tinyrecurrentunet_amd.engine_bf16 import Act16, TRUNetEngineBF16
+    from tinyrecurrentunet_amd.network import TRUNet
+    torch.manual_seed(3)
+    net = TRUNet(input_size=4).cuda().train()
+    N = 777
+    g = torch.Generator(device=DEV)
+    g.manual_seed(9)
+    x = torch.randn(N, 4, 257, generator=g, device=DEV)
+    gout = torch.randn(N, 8, 257, generator=g, device=DEV) / N
+    e16 = TRUNetEngineBF16(net)
+    _, ctx = e16.forward(x, True, record=True)
+    acts, N_, NP, w, gen = ctx
+    g16 = {p: t.clone() for p, t in e16.backward(ctx, gout).items()}
+    # the same forward state as fp32 tensors
+    lib, st = L.lib(), L.stream()
+    acts32 = {}
+    for k, a in acts.items():
+        if isinstance(a, Act16):
+            t = torch.empty((a.C, a.L, NP), device=DEV)
+            check(lib.trunet_bf16_to_frames_last(ptr16(a.t), ptr(t), a.C, a.L, NP, st), "to_frames_last")
+            acts32[k] = Act(t, a.C, a.L, a.bn)
+        else:
+            acts32[k] = a
+    acts32["enc5"], acts32["fgru"] = acts["enc5.f32"], acts["fgru.f32"]
+    e32 = TRUNetEngine(net)
+    g32 = e32.backward((acts32, N, NP, w, gen), gout)
+    worst = 0.0
+    for n, p in net.named_parameters():
+        if n.startswith("TGRU."):
+            continue
+        a, b = g16[p], g32[p]
+        if b.norm().item() < 1e-5 * b.numel() ** 0.5:      # conv biases in front of a BatchNorm: analytically zero
+            assert a.norm().item() < 2e-2, (n, a.norm().item())
+            continue
+        # a BatchNorm weight followed by ReLU -> conv -> BatchNorm has an analytically vanishing gradient while its bias
+        # is 0 (the next BatchNorm removes the scale): measure it against the scale of its sibling bias gradient
+        scale = b.norm().item()
+        if n.endswith(".1.weight"):
+            scale = max(scale, g32[dict(net.named_parameters())[n[:-6] + "bias"]].norm().item())
+        e = (a - b).norm().item() / (scale + 1e-30)
+        print("%-50s %.3e   |g| %.3e" % (n, e, b.norm().item()))
+        worst = max(worst, e)
+        assert e < 5e-2, "%s: bf16 backward differs from the fp32 backward of the same forward state by %.3e" % (n, e)
+    print("worst relative L2 over the parameter gradients: %.3e" % worst)
+
+
+@pytest.mark.parametrize("cin,N", [(4, 501), (3, 130)])
+def test_bf16_network_forward_and_gradients_vs_fp32(cin, N):
+    """SURVEY 8d gate for configs[2].  The survey proposed "forward <= 1e-2 relative"; measured, the randomly initialised
+    network turns ONE bf16 rounding per layer (the weights alone, fp32 everywhere else) into 1.7e-2 at the output and
+    27-41 % in the deep layers' gradients -- every perturbation flips ReLU masks downstream -- so three roundings per layer
+    (stored activation, MFMA operand, weight) give 3.0-3.3e-2.  The gate is therefore relative to that yardstick: forward
+    <= 5e-2 and <= 2.5x the weights-only deviation; every gradient tensor within 2x the weights-only deviation (+ 0.1) and
+    positively aligned with the fp32 gradient (cosine >= 0.6); the loss itself within 1 % (next test)."""
+    from tinyrecurrentunet_amd.network import TRUNet
+    f32, b16 = _pair(cin)
+    f32w = TRUNet(input_size=cin).cuda().train()
+    f32w.load_state_dict(f32.state_dict())
+    with torch.no_grad():
+        for p in f32w.parameters():
+            if p.dim() > 1:
+                p.copy_(_rb(p))
+    g = torch.Generator(device=DEV)
+    g.manual_seed(5)
+    x = torch.randn(N, cin, 257, generator=g, device=DEV)
+    gout = torch.randn(N, 8, 257, generator=g, device=DEV) / N
+    ys = []
+    for net in (f32, f32w, b16):
+        y = net(x)
+        y.backward(gout)
+        ys.append(y.detach())
+    rel, relw = _l2(ys[2], ys[0]), _l2(ys[1], ys[0])
+    print("forward: bf16 vs fp32 %.3e, fp32 with bf16-rounded weights vs fp32 %.3e" % (rel, relw))
+    assert rel < 5e-2 and rel < 2.5 * relw, (rel, relw)
+    bad = []
+    for (n, p), (_, pw), (_, q) in zip(f32.named_parameters(), f32w.named_parameters(), b16.named_parameters()):
+        if n.startswith("TGRU."):
+            continue
+        assert q.grad is not None, n
+        if p.grad.norm().item() < 1e-6 * p.grad.numel() ** 0.5:        # conv biases in front of a BatchNorm: ~0
+            assert q.grad.norm().item() < 2e-2, n
+            continue
+        e, ew = _l2(q.grad, p.grad), _l2(pw.grad, p.grad)
+        cos = (q.grad * p.grad).sum().item() / (q.grad.norm().item() * p.grad.norm().item() + 1e-30)
+        sib = dict(f32.named_parameters())[n[:-6] + "bias"].grad.norm().item() if n.endswith(".1.weight") else 0.0
+        if p.grad.norm().item() < 0.05 * sib:
+            # analytically vanishing while the BatchNorm bias is 0 (its scale is removed by the next BatchNorm): only small
+            if not (q.grad - p.grad).norm().item() < 0.5 * sib:
+                bad.append((n, e, ew, cos, sib))
+            continue
+        if not (e < 2 * ew + 0.1 and cos > 0.6):
+            bad.append((n, e, ew, cos))
+    assert not bad, bad
+    # BatchNorm running statistics updated like fp32
+    for (n, p), (_, q) in zip(f32.named_buffers(), b16.named_buffers()):
+        if n.startswith("TGRU.") or "num_batches" in n:
+            continue
+        assert _l2(q.float(), p.float()) < 3e-2, n
+
+
+def test_bf16_loss_within_one_percent_and_repeatable():
+    from tinyrecurrentunet_amd.stft_loss import MultiResolutionSTFTLoss
+    from tinyrecurrentunet_amd.util import loss_fn
+    f32, b16 = _pair(4)
+    mr = MultiResolutionSTFTLoss(fft_sizes=[512, 1024, 2048], hop_sizes=[50, 120, 240], win_lengths=[240, 600, 1200],
+                                 window="hann_window", sc_lambda=0.5, mag_lambda=0.5, band="full").cuda()
+    g = torch.Generator(device=DEV)
+    g.manual_seed(11)
+    clean = 0.1 * torch.randn(4, 1, 16000, generator=g, device=DEV)
+    noisy = clean + 0.05 * torch.randn(4, 1, 16000, generator=g, device=DEV)
+    l32, d32 = loss_fn(f32, (clean, noisy), 1, 1.0, 1.0, mr)
+    l16, d16 = loss_fn(b16, (clean, noisy), 1, 1.0, 1.0, mr)
+    assert abs(l16.item() - l32.item()) < 1e-2 * abs(l32.item()), (l16.item(), l32.item())
+    for k in d32:
+        assert abs(d16[k].item() - d32[k].item()) < 2e-2 * abs(d32[k].item()) + 1e-5, (k, d16[k].item(), d32[k].item())
+    l16.backward()
+    g1 = [p.grad.clone() for n, p in b16.named_parameters() if p.grad is not None]
+    b16.zero_grad(set_to_none=True)
+    for m in b16.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.reset_running_stats()
+    l16b, _ = loss_fn(b16, (clean, noisy), 1, 1.0, 1.0, mr)
+    l16b.backward()
+    g2 = [p.grad for n, p in b16.named_parameters() if p.grad is not None]
+    assert l16b.item() == l16.item()
+    assert all(torch.equal(a, b) for a, b in zip(g1, g2)), "bf16 step is not bitwise repeatable"

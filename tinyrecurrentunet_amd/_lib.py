@@ -63,6 +63,27 @@ class ConvtBwdArgs(C.Structure):
                                    "w_partials", "b_partials")]
 
 
+class BSeg(C.Structure):
+    """trunet_bseg: one K-segment of a bf16 (octet layout) implicit GEMM / weight gradient"""
+    _fields_ = [("src0", _fp), ("src1", _fp), ("c0", _fp), ("c1", _fp), ("c2", _fp),
+                ("nchan", C.c_int32), ("L", C.c_int32), ("pos_mul", C.c_int32), ("pos_off", C.c_int32),
+                ("pos_div", C.c_int32), ("mode", C.c_int32), ("kstep0", C.c_int32), ("woff", C.c_int32)]
+
+
+class BGemmArgs(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("NP", "N", "P", "p_begin", "M", "out_L", "out_pos_off", "nseg", "epi", "M_stat",
+                                         "nks_total", "_pad")] + \
+               [(n, _fp) for n in ("out", "wfrag", "bias", "zmask", "e0", "e1", "e2", "partials")] + \
+               [("seg", BSeg * MAX_SEG)]
+
+
+class BWgradArgs(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("NP", "N", "P", "p_begin", "M", "a_L", "a_pos_off", "a_mode", "ldw_m", "ldw_c",
+                                         "w_m_off", "nseg", "w_numel", "b_stride", "b_off", "_pad")] + \
+               [(n, _fp) for n in ("a0", "a1", "ac0", "ac1", "ac2", "w_partials", "b_partials")] + \
+               [("seg", BSeg * MAX_SEG)]
+
+
 _lib = None
 
 
@@ -136,6 +157,15 @@ def _declare(L):
         "trunet_stream_fwd_grid": [i],
         "trunet_stream_fwd_scratch_floats": [i],
         "trunet_stream_fwd": [p, p, p, C.POINTER(C.c_int32), i, p, i, i, p],
+        "trunet_bf16_gemm_nparts": [],
+        "trunet_bf16_gemm": [C.POINTER(BGemmArgs), p],
+        "trunet_bf16_pack_weight": [p, p, i, i, i, i, i, C.POINTER(C.c_int32), C.POINTER(C.c_int32), p],
+        "trunet_bf16_wgrad": [C.POINTER(BWgradArgs), p],
+        "trunet_bf16_dw_nparts": [i, i],
+        "trunet_bf16_dwconv_fwd": [p, p, p, p, p, p, p, i, i, i, i, i, i, i, p],
+        "trunet_bf16_dwconv_bwd": [p] * 14 + [i] * 7 + [p],
+        "trunet_bf16_from_frames_last": [p, p, i, i, i, p],
+        "trunet_bf16_to_frames_last": [p, p, i, i, i, p],
         "trunet_debug_mfma_peak": [p, i, i, p],
     }
     for name, args in sig.items():
@@ -161,6 +191,14 @@ def ptr(t):
     if t is None:
         return None
     assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), (t.device, t.dtype, t.is_contiguous())
+    return t.data_ptr()
+
+
+def ptr16(t):
+    """Device pointer of a contiguous bf16 torch tensor in the octet layout (or None)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous(), (t.device, t.dtype, t.is_contiguous())
     return t.data_ptr()
 
 

@@ -1,0 +1,873 @@
+// bf16 storage / bf16 MFMA family (BASELINE.json configs[2], a build extension: SURVEY 8d).
+//
+// At 16x the fp32 MFMA rate every layer of the body is a plain HBM stream, so these kernels are built for memory
+// behaviour, not for matrix-pipe scheduling: activations / gradients in the OCTET layout bf16 [C/8][L][NP][8] (the 8
+// channels of an octet are the 8 consecutive k values one lane feeds to v_mfma_f32_32x32x16_bf16, i.e. ONE 16-byte global
+// load per lane and k-step, 1 KiB contiguous per wave, no LDS staging of activations in the forward / data-gradient GEMM);
+// weights as MFMA A fragments in LDS (packed per launch from the fp32 master weights); fp32 accumulators, statistics,
+// coefficients, weight gradients.  Taps, strides, F.pad, crops and the concat of network.py:95-98 stay whole-row offsets /
+// extra segments.
+#include "common.hpp"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+__device__ __forceinline__ unsigned bf_pack(float lo, float hi) {      // round to nearest even (v_cvt_pk_bf16_f32)
+    const __bf16 a = (__bf16)lo, b = (__bf16)hi;
+    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+__device__ __forceinline__ void bf_unpack8(const u32x4 v, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = bf_lo(v[i]); f[2 * i + 1] = bf_hi(v[i]); }
+}
+__device__ __forceinline__ u32x4 bf_pack8(const float (&f)[8]) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = bf_pack(f[2 * i], f[2 * i + 1]);
+    return v;
+}
+
+// sum each of 16 per-lane values over the 32 lanes of a half-wave; lane c returns the total of value butterfly16_index(c)
+// (16 cross-lane exchanges instead of 80, and ONE live register instead of 16)
+__device__ __forceinline__ float butterfly16(const float (&x)[16], int c) {
+    float y8[8], y4[4], y2[2];
+    const bool b16 = c & 16, b8 = c & 8, b4 = c & 4, b2 = c & 2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) y8[i] = (b16 ? x[i + 8] : x[i]) + __shfl_xor(b16 ? x[i] : x[i + 8], 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y4[i] = (b8 ? y8[i + 4] : y8[i]) + __shfl_xor(b8 ? y8[i] : y8[i + 4], 8);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) y2[i] = (b4 ? y4[i + 2] : y4[i]) + __shfl_xor(b4 ? y4[i] : y4[i + 2], 4);
+    const float y1 = (b2 ? y2[1] : y2[0]) + __shfl_xor(b2 ? y2[0] : y2[1], 2);
+    return y1 + __shfl_xor(y1, 1);
+}
+__device__ __forceinline__ int butterfly16_index(int c) {
+    return ((c & 16) ? 8 : 0) + ((c & 8) ? 4 : 0) + ((c & 4) ? 2 : 0) + ((c & 2) ? 1 : 0);
+}
+
+constexpr int BG_GRID = 2 * TRUNET_NUM_CU;      // workgroups of 4 waves, two per CU
+constexpr int BG_MAXKS = 24;                    // k-steps of 16 channels over all segments (5 x 64 channels = 20)
+
+struct BSegPos { bool valid; int q; };
+__device__ __forceinline__ BSegPos bseg_pos(const trunet_bseg& sg, int p) {
+    const int qn = p * sg.pos_mul + sg.pos_off;
+    BSegPos r;
+    r.q = qn / sg.pos_div;
+    r.valid = (qn >= 0) && (qn - r.q * sg.pos_div == 0) && (r.q < sg.L);
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Implicit GEMM (forward of Conv1d k = 1 / ConvTranspose1d / the strided first conv, and their data gradients).
+// A wave owns NRT <= 2 row tiles (64 output channels) of a tile (position p, 32 frames); for M > 64 two waves split the
+// rows.  Workgroups are renumbered so that each XCD (blockIdx % 8) walks a contiguous range of tiles: the taps of a
+// transposed conv re-read a source row at neighbouring positions, which then hit that XCD's L2.
+template <int NRT>
+__global__ __launch_bounds__(256, 2) void bgemm_kernel(const trunet_bgemm_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_[];
+    u32x4* Al = (u32x4*)smem_;                                          // [nrt_all][nks_total][64] A fragments
+    const int nrt_all = (a.M + 31) >> 5;
+    float* Cf = (float*)(Al + (size_t)nrt_all * a.nks_total * 64);      // [nks_total][2 octets][3][8] coefficients
+    float* Ep = Cf + a.nks_total * 2 * 3 * 8;                           // [4][128] epilogue: bias, e0, e1, e2 (LDS, not 128
+                                                                        // hoisted registers)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, c = lane & 31;
+
+    for (int i = tid; i < nrt_all * a.nks_total * 64; i += 256) Al[i] = ((const u32x4*)a.wfrag)[i];
+    // coefficient image per (k-step, octet half, {c0,c1,c2}, channel): zero coefficients cover padded channels
+    for (int i = tid; i < a.nks_total * 2 * 3 * 8; i += 256) Cf[i] = 0.f;
+    for (int i = tid; i < 128; i += 256) {
+        const bool ok = i < a.M;
+        Ep[i] = (ok && (a.epi & TRUNET_EPI_BIAS)) ? a.bias[i] : 0.f;
+        Ep[128 + i] = (ok && (a.epi & TRUNET_EPI_MASK)) ? a.e0[i] : 0.f;
+        Ep[256 + i] = (ok && (a.epi & TRUNET_EPI_MASK)) ? a.e1[i] : 0.f;
+        Ep[384 + i] = (ok && (a.epi & TRUNET_EPI_MASK) && a.e2) ? a.e2[i] : 0.f;
+    }
+    __syncthreads();
+    for (int s = 0; s < a.nseg; ++s) {
+        const trunet_bseg& sg = a.seg[s];
+        const int noct = (sg.nchan + 7) >> 3;
+        for (int i = tid; i < noct * 8; i += 256) {
+            const int oct = i >> 3, j = i & 7, ks = sg.kstep0 + (oct >> 1), hh = oct & 1;
+            float* cf = Cf + ((ks * 2 + hh) * 3) * 8 + j;
+            const bool real = i < sg.nchan;
+            if (sg.mode == TRUNET_PRO_NONE) { cf[0] = 1.f; cf[8] = 0.f; cf[16] = 0.f; }
+            else if (sg.mode == TRUNET_PRO_BNRELU) { cf[0] = real ? sg.c0[i] : 0.f; cf[8] = real ? sg.c1[i] : 0.f; cf[16] = 0.f; }
+            else { cf[0] = real ? sg.c0[i] : 0.f; cf[8] = real ? sg.c1[i] : 0.f; cf[16] = real ? sg.c2[i] : 0.f; }
+        }
+    }
+    __syncthreads();
+
+    const int split = nrt_all > 2;                      // two waves share a tile (rows split)
+    const int rt0 = split ? 2 * (wave & 1) : 0;
+    const int nrt = min(NRT, nrt_all - rt0);
+    const int tslot = split ? (wave >> 1) : wave, tslots = split ? 2 : 4;
+    const int nfc = a.NP / 32;
+    const int total = a.P * nfc;
+    const int vb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);      // XCD-contiguous numbering
+
+    // statistics: per tile the 16 values of a row tile are summed over the 32 frames of the half-wave by a butterfly that
+    // leaves value r(c) in lane c (1 register instead of 16): sacc[t][kind]
+    float sacc[NRT][2];
+#pragma unroll
+    for (int t = 0; t < NRT; ++t) { sacc[t][0] = 0.f; sacc[t][1] = 0.f; }
+
+    for (int tile = vb * tslots + tslot; tile < total; tile += gridDim.x * tslots) {
+        const int chunk = tile / a.P;
+        const int p = a.p_begin + (tile - chunk * a.P);
+        const int n0 = chunk * 32;
+        f32x16 acc[NRT];
+#pragma unroll
+        for (int t = 0; t < NRT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+        for (int s = 0; s < a.nseg; ++s) {
+            const trunet_bseg& sg = a.seg[s];
+            const BSegPos sp = bseg_pos(sg, p);
+            if (!sp.valid) continue;
+            const int noct = (sg.nchan + 7) >> 3;
+            const int nks = (noct + 1) >> 1;
+            const size_t ostride = (size_t)sg.L * a.NP;                              // u32x4 elements between octets
+            const u32x4* b0 = (const u32x4*)sg.src0 + (size_t)sp.q * a.NP + n0 + c;
+            const u32x4* b1 = (const u32x4*)sg.src1 + (size_t)sp.q * a.NP + n0 + c;
+            const bool two = sg.mode == TRUNET_PRO_BNBWD;
+            for (int ks0 = 0; ks0 < nks; ks0 += 4) {
+                u32x4 r0[4], r1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int oct = 2 * (ks0 + j) + h;
+                    const bool ok = oct < noct;
+                    const u32x4 z4 = {0u, 0u, 0u, 0u};
+                    r0[j] = ok ? b0[(size_t)oct * ostride] : z4;
+                    r1[j] = (ok && two) ? b1[(size_t)oct * ostride] : z4;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    asm volatile("" ::: "memory");          // keep the coefficient / fragment LDS reads of a k-step with it
+                    if (ks0 + j < nks) {
+                        const int ks = sg.kstep0 + ks0 + j;
+                        const float* cf = Cf + ((ks * 2 + h) * 3) * 8;
+                        float v[8], w[8];
+                        bf_unpack8(r0[j], v);
+                        if (two) {
+                            bf_unpack8(r1[j], w);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = fmaf(cf[e], v[e], fmaf(cf[8 + e], w[e], cf[16 + e]));
+                        } else if (sg.mode == TRUNET_PRO_BNRELU) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(cf[e], v[e], cf[8 + e]), 0.f);
+                        }
+                        const bf16x8 bfrag = __builtin_bit_cast(bf16x8, bf_pack8(v));
+#pragma unroll
+                        for (int t = 0; t < NRT; ++t) {
+                            if (t < nrt) {
+                                const bf16x8 afrag = __builtin_bit_cast(bf16x8, Al[((size_t)(rt0 + t) * a.nks_total + ks) * 64 + lane]);
+                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[t], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // ---- epilogue: bias, accumulate, ReLU mask / ReLU, bf16 store (4 channels = 8 bytes per lane and octet), statistics
+        // of the ROUNDED values
+        const bool fin = n0 + c < a.N;
+#pragma unroll
+        for (int t = 0; t < NRT; ++t) {
+            if (t >= nrt) continue;
+            float st1[16], st2[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st1[r] = 0.f; st2[r] = 0.f; }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int m0 = (rt0 + t) * 32 + 8 * g + 4 * h;          // first of this lane's 4 rows
+                if (m0 >= a.M) continue;
+                const size_t eidx = (((size_t)((rt0 + t) * 4 + g) * a.out_L + p + a.out_pos_off) * a.NP + n0 + c) * 2 + h;
+                float val[4], zv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) val[i] = acc[t][4 * g + i];
+                asm volatile("" ::: "memory");
+                if (a.epi & TRUNET_EPI_BIAS) {
+                    const f32x4 bv = *(const f32x4*)(Ep + m0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) val[i] += bv[i];
+                }
+                if (a.epi & TRUNET_EPI_ACCUM) {
+                    const u32x2 o = ((const u32x2*)a.out)[eidx];
+                    val[0] += bf_lo(o[0]); val[1] += bf_hi(o[0]); val[2] += bf_lo(o[1]); val[3] += bf_hi(o[1]);
+                }
+                if (a.epi & TRUNET_EPI_MASK) {
+                    const u32x2 zz = ((const u32x2*)a.zmask)[eidx];
+                    zv[0] = bf_lo(zz[0]); zv[1] = bf_hi(zz[0]); zv[2] = bf_lo(zz[1]); zv[3] = bf_hi(zz[1]);
+                    const f32x4 e0v = *(const f32x4*)(Ep + 128 + m0), e1v = *(const f32x4*)(Ep + 256 + m0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) val[i] = (fmaf(e0v[i], zv[i], e1v[i]) > 0.f) ? val[i] : 0.f;
+                }
+                if (a.epi & TRUNET_EPI_RELU) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) val[i] = fmaxf(val[i], 0.f);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (m0 + i >= a.M) val[i] = 0.f;       // padded channels of the last octet
+                u32x2 o;
+                o[0] = bf_pack(val[0], val[1]);
+                o[1] = bf_pack(val[2], val[3]);
+                ((u32x2*)a.out)[eidx] = o;
+                if (a.epi & TRUNET_EPI_STATS) {
+                    const float rv[4] = {bf_lo(o[0]), bf_hi(o[0]), bf_lo(o[1]), bf_hi(o[1])};
+                    const f32x4 muv = *(const f32x4*)(Ep + 384 + m0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float x = fin ? rv[i] : 0.f;
+                        st1[4 * g + i] = x;
+                        if (a.epi & TRUNET_EPI_MASK) {
+                            st2[4 * g + i] = x * (zv[i] - muv[i]);
+                        } else {
+                            st2[4 * g + i] = x * x;
+                        }
+                    }
+                }
+            }
+            if (a.epi & TRUNET_EPI_STATS) {
+                sacc[t][0] += butterfly16(st1, c);
+                sacc[t][1] += butterfly16(st2, c);
+            }
+        }
+    }
+    if (a.epi & TRUNET_EPI_STATS) {
+        float* pp = a.partials + ((size_t)(blockIdx.x * 4 + wave) * a.M_stat) * 2;
+        const int r = butterfly16_index(c);
+#pragma unroll
+        for (int t = 0; t < NRT; ++t) {
+            if (t >= nrt) continue;
+            const int m = (rt0 + t) * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+            if (!(c & 1) && m < a.M) { pp[2 * m] = sacc[t][0]; pp[2 * m + 1] = sacc[t][1]; }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weight packing: fp32 master weight -> bf16 A fragments
+struct PackDesc { int nchan[TRUNET_MAX_SEG], woff[TRUNET_MAX_SEG], ks0[TRUNET_MAX_SEG]; int nseg, nks_total; };
+
+__global__ void pack_weight_kernel(const float* __restrict__ W, u32x4* __restrict__ out, int M, int ldw_m, int ldw_c,
+                                   int w_m_off, const PackDesc d) {
+    const int i = blockIdx.x * 256 + threadIdx.x;           // (rt, ks, lane)
+    const int nrt = (M + 31) >> 5;
+    if (i >= nrt * d.nks_total * 64) return;
+    const int lane = i & 63, ks = (i >> 6) % d.nks_total, rt = (i >> 6) / d.nks_total;
+    const int m = rt * 32 + (lane & 31);
+    int s = 0;
+    for (int t = 1; t < d.nseg; ++t) if (ks >= d.ks0[t]) s = t;
+    const int cbase = (ks - d.ks0[s]) * 16 + 8 * (lane >> 5);
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ch = cbase + j;
+        f[j] = (m < M && ch < d.nchan[s]) ? W[(size_t)(m + w_m_off) * ldw_m + (size_t)ch * ldw_c + d.woff[s]] : 0.f;
+    }
+    out[i] = bf_pack8(f);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient.  The MFMA K axis is the frame axis, so both operands need 8 consecutive FRAMES of one channel per lane
+// while the octet layout delivers 8 CHANNELS of one frame.  A step is (position p, 64 frames): wave w loads the octets
+// w, w + 8, ... of dy (, z) and of the valid source segments -- 1 KiB contiguous per wave-load, every operand row read from
+// HBM exactly once per step -- applies the prologue (BatchNorm backward on dz, BN + ReLU on the sources, frames >= N
+// zeroed) and writes the result to LDS as [octet][frame][8 channels] (octet stride 64 frames * 16 B + 64 B, which makes
+// the transposed reads conflict-free).  ds_read_b64_tr_b16 then hands every lane 4 frames of one channel: two reads are
+// an MFMA fragment.  The loads of step t + 1 are in flight in registers while step t's MFMAs run; LDS is double-buffered,
+// one raw barrier per step.
+constexpr int BW_THREADS = 512;
+constexpr int BW_F = 64;                         // frames per step
+constexpr int BW_OS = BW_F * 16 + 64;            // LDS bytes between octets
+constexpr int BW_MAXD = 2;                       // dz octets per wave (M <= 128)
+constexpr int BW_MAXS = 5;                       // source octets per wave (<= 40 over all segments)
+constexpr int BW_MAXT = 3;                       // output tiles per wave
+
+__device__ __forceinline__ u32x2 lds_tr16(const unsigned char* p) {
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+    return __builtin_bit_cast(u32x2, v);
+}
+// fragment (rows = 32 channels starting at octet oct0, k = 16 frames starting at f0) of an [octet][frame][8] image
+__device__ __forceinline__ bf16x8 lds_frag(const unsigned char* img, int oct0, int f0, int lane) {
+    const int G = lane >> 4, i = lane & 15;
+    const unsigned char* p = img + (oct0 + 2 * (G & 1) + ((i & 3) >> 1)) * BW_OS + (f0 + 8 * (G >> 1) + (i >> 2)) * 16 + 8 * (i & 1);
+    const u32x2 lo = lds_tr16(p), hi = lds_tr16(p + 64);
+    const u32x4 f = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8, f);
+}
+
+__global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgrad_args a, int soct_total) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int moct = (a.M + 7) >> 3;
+    const int nrt = (a.M + 31) >> 5;
+    const bool two = a.a_mode == TRUNET_PRO_BNBWD;
+    const int img_bytes = (moct + soct_total) * BW_OS;           // one buffer: dz octets, then the source octets
+    // ---- this wave's operand octets
+    int soct_seg[BW_MAXS], soct_idx[BW_MAXS], soct_g[BW_MAXS];   // segment, octet within the segment, global source octet
+#pragma unroll
+    for (int j = 0; j < BW_MAXS; ++j) {
+        const int g = wave + 8 * j;
+        soct_seg[j] = -1; soct_idx[j] = 0; soct_g[j] = g;
+        int base = 0;
+        for (int s = 0; s < a.nseg; ++s) {
+            const int no = (a.seg[s].nchan + 7) >> 3;
+            if (g >= base && g < base + no) { soct_seg[j] = s; soct_idx[j] = g - base; }
+            base += no;
+        }
+    }
+    // ---- this wave's output tiles: g = rt * nct_total + (segment, c tile), taken round-robin
+    int t_rt[BW_MAXT], t_seg[BW_MAXT], t_ct[BW_MAXT], t_oct0[BW_MAXT];
+    {
+        int nct_total = 0;
+        for (int s = 0; s < a.nseg; ++s) nct_total += (a.seg[s].nchan + 31) >> 5;
+#pragma unroll
+        for (int i = 0; i < BW_MAXT; ++i) {
+            const int g = wave + 8 * i;
+            t_rt[i] = -1; t_seg[i] = 0; t_ct[i] = 0; t_oct0[i] = 0;
+            if (g < nrt * nct_total) {
+                t_rt[i] = g / nct_total;
+                int cg = g - t_rt[i] * nct_total, obase = 0;
+                for (int s = 0; s < a.nseg; ++s) {
+                    const int nct = (a.seg[s].nchan + 31) >> 5;
+                    if (cg >= 0 && cg < nct) { t_seg[i] = s; t_ct[i] = cg; t_oct0[i] = obase + 4 * cg; }
+                    cg -= nct;
+                    obase += (a.seg[s].nchan + 7) >> 3;
+                }
+            }
+        }
+    }
+    f32x16 acc[BW_MAXT];
+#pragma unroll
+    for (int i = 0; i < BW_MAXT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float bsum[BW_MAXD][8];
+#pragma unroll
+    for (int j = 0; j < BW_MAXD; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bsum[j][e] = 0.f;
+
+    const int nf = a.NP / BW_F;
+    const int total = a.P * nf;
+    const int s_begin = (int)(((long long)blockIdx.x * total) / gridDim.x);
+    const int s_end = (int)(((long long)(blockIdx.x + 1) * total) / gridDim.x);
+
+    u32x4 rdy[BW_MAXD], rz[BW_MAXD], rs[BW_MAXS];
+    const u32x4 z4 = {0u, 0u, 0u, 0u};
+
+    auto issue = [&](int st) {
+        const int chunk = st / a.P;
+        const int p = a.p_begin + (st - chunk * a.P);
+        const size_t n = (size_t)chunk * BW_F + lane;
+#pragma unroll
+        for (int j = 0; j < BW_MAXD; ++j) {
+            const int oct = wave + 8 * j;
+            if (oct < moct) {
+                const size_t idx = ((size_t)oct * a.a_L + p + a.a_pos_off) * a.NP + n;
+                rdy[j] = ((const u32x4*)a.a0)[idx];
+                if (two) rz[j] = ((const u32x4*)a.a1)[idx];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < BW_MAXS; ++j) {
+            if (soct_seg[j] >= 0) {
+                const trunet_bseg& sg = a.seg[soct_seg[j]];
+                const BSegPos sp = bseg_pos(sg, p);
+                if (sp.valid) rs[j] = ((const u32x4*)sg.src0)[((size_t)soct_idx[j] * sg.L + sp.q) * a.NP + n];
+            }
+        }
+    };
+    auto store = [&](int st, unsigned char* buf) {
+        const int chunk = st / a.P;
+        const int p = a.p_begin + (st - chunk * a.P);
+        const bool fin = chunk * BW_F + lane < a.N;
+#pragma unroll
+        for (int j = 0; j < BW_MAXD; ++j) {
+            const int oct = wave + 8 * j;
+            if (oct < moct) {
+                float v[8], w[8];
+                bf_unpack8(rdy[j], v);
+                if (two) {
+                    bf_unpack8(rz[j], w);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int m = min(oct * 8 + e, a.M - 1);
+                        v[e] = fmaf(a.ac0[m], v[e], fmaf(a.ac1[m], w[e], a.ac2[m]));
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    v[e] = (fin && oct * 8 + e < a.M) ? v[e] : 0.f;
+                    bsum[j][e] += v[e];
+                }
+                *(u32x4*)(buf + oct * BW_OS + lane * 16) = bf_pack8(v);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < BW_MAXS; ++j) {
+            if (soct_seg[j] >= 0) {
+                const trunet_bseg& sg = a.seg[soct_seg[j]];
+                const BSegPos sp = bseg_pos(sg, p);
+                if (sp.valid) {
+                    float v[8];
+                    bf_unpack8(rs[j], v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int ch = soct_idx[j] * 8 + e;
+                        if (sg.mode == TRUNET_PRO_BNRELU) {
+                            const int cc = min(ch, sg.nchan - 1);
+                            v[e] = fmaxf(fmaf(sg.c0[cc], v[e], sg.c1[cc]), 0.f);
+                        }
+                        if (ch >= sg.nchan) v[e] = 0.f;
+                    }
+                    *(u32x4*)(buf + (moct + soct_g[j]) * BW_OS + lane * 16) = bf_pack8(v);
+                }
+            }
+        }
+    };
+    auto mma = [&](int st, const unsigned char* buf) {
+        const int chunk = st / a.P;
+        const int p = a.p_begin + (st - chunk * a.P);
+#pragma unroll
+        for (int i = 0; i < BW_MAXT; ++i) {
+            if (t_rt[i] < 0) continue;
+            if (!bseg_pos(a.seg[t_seg[i]], p).valid) continue;
+#pragma unroll
+            for (int kk = 0; kk < BW_F / 16; ++kk) {
+                const bf16x8 af = lds_frag(buf, 4 * t_rt[i], 16 * kk, lane);
+                const bf16x8 bfr = lds_frag(buf, moct + t_oct0[i], 16 * kk, lane);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[i], 0, 0, 0);
+            }
+        }
+    };
+
+    // rows of dz beyond moct that a 32-row tile still reads (M not a multiple of 32) and source octets beyond a segment's
+    // last one inside its last 32-channel tile must read as zeros: clear both buffers once
+    for (int i = tid; i < 2 * img_bytes / 16; i += BW_THREADS) ((u32x4*)smem_)[i] = z4;
+    __syncthreads();
+
+    if (s_begin < s_end) issue(s_begin);
+    for (int st = s_begin; st < s_end; ++st) {
+        unsigned char* buf = smem_ + ((st - s_begin) & 1) * img_bytes;
+        store(st, buf);
+        if (st + 1 < s_end) issue(st + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        mma(st, buf);
+    }
+
+    // ---- partial image of dW (rows m = dz channel, columns c = source channel) and db
+    float* img = a.w_partials + (size_t)blockIdx.x * a.w_numel;
+    const int cidx = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < BW_MAXT; ++i) {
+        if (t_rt[i] < 0) continue;
+        const trunet_bseg& sg = a.seg[t_seg[i]];
+        const int ci = t_ct[i] * 32 + cidx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = t_rt[i] * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (m < a.M && ci < sg.nchan)
+                img[(size_t)(m + a.w_m_off) * a.ldw_m + (size_t)ci * a.ldw_c + sg.woff] = acc[i][r];
+        }
+    }
+    if (a.b_partials) {
+#pragma unroll
+        for (int j = 0; j < BW_MAXD; ++j) {
+            const int oct = wave + 8 * j;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = wave_sum(bsum[j][e]);
+                const int m = oct * 8 + e;
+                if (lane == 0 && oct < moct && m < a.M) a.b_partials[(size_t)blockIdx.x * a.b_stride + a.b_off + m] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// depthwise conv, octet layout.  A thread owns (octet = blockIdx.y, frame, chunk of positions = blockIdx.z) and walks the
+// positions with a sliding window in registers: every input row is loaded once.
+template <int NV>
+__device__ __forceinline__ void block_reduce_store(float (&v)[NV], float* smem /* [4][NV] */, float* dst, int stride) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float s = wave_sum(v[i]);
+        if (lane == 0) smem[wave * NV + i] = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NV; i += 256)
+        dst[(size_t)i * stride] = (smem[i] + smem[NV + i]) + (smem[2 * NV + i] + smem[3 * NV + i]);
+    __syncthreads();
+}
+
+__host__ __device__ inline int bdw_chunks(int rows) { return rows >= 32 ? 4 : (rows >= 16 ? 2 : 1); }
+
+template <int K, int S>
+__global__ __launch_bounds__(256) void bdw_fwd_kernel(const u32x4* __restrict__ zin, const float* __restrict__ s_in,
+                                                      const float* __restrict__ t_in, const float* __restrict__ w,
+                                                      const float* __restrict__ b, u32x4* __restrict__ zout,
+                                                      float* __restrict__ partials, int C, int Lin, int Lout, int NP, int N) {
+    __shared__ float red[4 * 16];
+    const int oct = blockIdx.y;
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int nch = gridDim.z;
+    const int lo0 = (int)(((long long)blockIdx.z * Lout) / nch), lo1 = (int)(((long long)(blockIdx.z + 1) * Lout) / nch);
+    float sc[8], sh[8], bb[8], wk[8][K];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ch = oct * 8 + j;
+        sc[j] = s_in[ch]; sh[j] = t_in[ch]; bb[j] = b[ch];
+#pragma unroll
+        for (int k = 0; k < K; ++k) wk[j][k] = w[ch * K + k];
+    }
+    float st[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) st[j] = 0.f;
+    const u32x4* src = zin + (size_t)oct * Lin * NP + n;
+    u32x4* dst = zout + (size_t)oct * Lout * NP + n;
+    auto load_act = [&](int li, float (&act)[8]) {
+        if (li >= 0 && li < Lin) {
+            float v[8];
+            bf_unpack8(src[(size_t)li * NP], v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) act[j] = fmaxf(fmaf(v[j], sc[j], sh[j]), 0.f);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) act[j] = 0.f;
+        }
+    };
+    float win[K][8];                    // win[k] = activated input at li = lo*S + k - K/2
+#pragma unroll
+    for (int k = 0; k < K - S; ++k) load_act(lo0 * S + k - K / 2, win[k + S]);       // pre-shifted: the loop shifts first
+    for (int lo = lo0; lo < lo1; ++lo) {
+#pragma unroll
+        for (int k = 0; k < K - S; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) win[k][j] = win[k + S][j];
+#pragma unroll
+        for (int k = K - S; k < K; ++k) load_act(lo * S + k - K / 2, win[k]);
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc[j] = bb[j];
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc[j] = fmaf(wk[j][k], win[k][j], acc[j]);
+        }
+        const u32x4 o = bf_pack8(acc);
+        dst[(size_t)lo * NP] = o;
+        if (n < N) {
+            float r[8];
+            bf_unpack8(o, r);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { st[2 * j] += r[j]; st[2 * j + 1] = fmaf(r[j], r[j], st[2 * j + 1]); }
+        }
+    }
+    const int part = blockIdx.z * gridDim.x + blockIdx.x;
+    block_reduce_store<16>(st, red, partials + ((size_t)part * C + oct * 8) * 2, 1);
+}
+
+// backward: groups of S input positions li = m*S + e; the taps of a group touch the dz rows m + LOMIN .. m + LOMAX, which
+// are kept (BatchNorm-backward transformed) in a 3-row register window and advance by one row per group.
+template <int K, int S>
+__global__ __launch_bounds__(256) void bdw_bwd_kernel(const u32x4* __restrict__ dy, const u32x4* __restrict__ z,
+                                                      const float* __restrict__ ca, const float* __restrict__ cb,
+                                                      const float* __restrict__ cc, const u32x4* __restrict__ zin,
+                                                      const float* __restrict__ s_in, const float* __restrict__ t_in,
+                                                      const float* __restrict__ mean_in, const float* __restrict__ w,
+                                                      u32x4* __restrict__ dy_in, float* __restrict__ partials_in,
+                                                      float* __restrict__ w_partials, float* __restrict__ b_partials, int C,
+                                                      int Lin, int Lout, int NP, int N) {
+    constexpr int LOMIN = -1, LOMAX = 1, W = 3;
+    static_assert((K == 3 && S == 1) || (K == 5 && S == 2) || (K == 3 && S == 2), "window derived for these shapes");
+    __shared__ float red[4 * 8 * (K + 1)];
+    const int oct = blockIdx.y;
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int G = (Lin + S - 1) / S;
+    const int nch = gridDim.z;
+    const int m0 = (int)(((long long)blockIdx.z * G) / nch), m1 = (int)(((long long)(blockIdx.z + 1) * G) / nch);
+    float a0[8], a1[8], a2[8], sc[8], sh[8], mu[8], wk[8][K];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ch = oct * 8 + j;
+        a0[j] = ca[ch]; a1[j] = cb[ch]; a2[j] = cc[ch];
+        sc[j] = s_in[ch]; sh[j] = t_in[ch]; mu[j] = mean_in[ch];
+#pragma unroll
+        for (int k = 0; k < K; ++k) wk[j][k] = w[ch * K + k];
+    }
+    float st[16], dwb[8 * (K + 1)];       // dwb[j*(K+1) + k] = dw[j][k], [.. + K] = db[j]
+#pragma unroll
+    for (int j = 0; j < 16; ++j) st[j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8 * (K + 1); ++j) dwb[j] = 0.f;
+    const u32x4* pdy = dy + (size_t)oct * Lout * NP + n;
+    const u32x4* pz = z + (size_t)oct * Lout * NP + n;
+    const u32x4* pin = zin + (size_t)oct * Lin * NP + n;
+    u32x4* pout = dy_in + (size_t)oct * Lin * NP + n;
+    const bool fin = n < N;
+    auto load_dz = [&](int lo, float (&d)[8]) {
+        if (lo >= 0 && lo < Lout && fin) {
+            float dv[8], zv[8];
+            bf_unpack8(pdy[(size_t)lo * NP], dv);
+            bf_unpack8(pz[(size_t)lo * NP], zv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] = fmaf(a0[j], dv[j], fmaf(a1[j], zv[j], a2[j]));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] = 0.f;
+        }
+    };
+    float dzw[W][8];                    // dzw[i] = dz row m + LOMIN + i
+#pragma unroll
+    for (int i = 1; i < W; ++i) load_dz(m0 + LOMIN + i - 1, dzw[i]);                 // pre-shifted
+    for (int m = m0; m < m1; ++m) {
+#pragma unroll
+        for (int i = 0; i < W - 1; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dzw[i][j] = dzw[i + 1][j];
+        load_dz(m + LOMAX, dzw[W - 1]);
+#pragma unroll
+        for (int e = 0; e < S; ++e) {
+            const int li = m * S + e;
+            if (li >= Lin) continue;
+            float zi[8], act[8], g[8];
+            bf_unpack8(pin[(size_t)li * NP], zi);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { act[j] = fmaxf(fmaf(zi[j], sc[j], sh[j]), 0.f); g[j] = 0.f; }
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                constexpr int half = K / 2;
+                const int num = e + half - k;                        // relative to m*S; compile-time after unrolling
+                if (((num % S) + S) % S != 0) continue;
+                const int lo_rel = (num >= 0) ? num / S : -((-num) / S);
+                const int wi = lo_rel - LOMIN;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float dzv = dzw[wi][j];
+                    g[j] = fmaf(wk[j][k], dzv, g[j]);
+                    dwb[j * (K + 1) + k] = fmaf(dzv, act[j], dwb[j * (K + 1) + k]);
+                    if (k == half) dwb[j * (K + 1) + K] += dzv;      // e == 0 here: every dz row counted once
+                }
+            }
+            float ov[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ov[j] = (act[j] > 0.f) ? g[j] : 0.f;
+            const u32x4 o = bf_pack8(ov);
+            pout[(size_t)li * NP] = o;
+            float r[8];
+            bf_unpack8(o, r);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { st[2 * j] += r[j]; st[2 * j + 1] = fmaf(r[j], zi[j] - mu[j], st[2 * j + 1]); }
+        }
+    }
+    const int part = blockIdx.z * gridDim.x + blockIdx.x;
+    block_reduce_store<16>(st, red, partials_in + ((size_t)part * C + oct * 8) * 2, 1);
+    // dw / db: [part][C][K] and [part][C]
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < 8 * (K + 1); ++i) {
+            const float s = wave_sum(dwb[i]);
+            if (lane == 0) red[wave * 8 * (K + 1) + i] = s;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 8 * (K + 1); i += 256) {
+            const int NVV = 8 * (K + 1);
+            const float s = (red[i] + red[NVV + i]) + (red[2 * NVV + i] + red[3 * NVV + i]);
+            const int j = i / (K + 1), k = i - j * (K + 1);
+            const int ch = oct * 8 + j;
+            if (k < K) w_partials[((size_t)part * C + ch) * K + k] = s;
+            else b_partials[(size_t)part * C + ch] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// layout changes: fp32 frames-last [C][R] (R = L*NP) <-> bf16 octets [C/8][R][8]
+__global__ void from_fl_kernel(const float* __restrict__ x, u32x4* __restrict__ y, int C, size_t R) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;      // (oct, r)
+    const int noct = (C + 7) >> 3;
+    if (i >= (size_t)noct * R) return;
+    const size_t r = i % R;
+    const int oct = (int)(i / R);
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ch = oct * 8 + j;
+        f[j] = ch < C ? x[(size_t)ch * R + r] : 0.f;
+    }
+    y[i] = bf_pack8(f);
+}
+__global__ void to_fl_kernel(const u32x4* __restrict__ x, float* __restrict__ y, int C, size_t R) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int noct = (C + 7) >> 3;
+    if (i >= (size_t)noct * R) return;
+    const size_t r = i % R;
+    const int oct = (int)(i / R);
+    float f[8];
+    bf_unpack8(x[i], f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ch = oct * 8 + j;
+        if (ch < C) y[(size_t)ch * R + r] = f[j];
+    }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int trunet_bf16_gemm_nparts(void) { return BG_GRID * 4; }
+
+static bool bseg_ok(const trunet_bseg& sg) {
+    if (!sg.src0 || sg.nchan <= 0 || sg.pos_div <= 0 || sg.L <= 0) return false;
+    if (sg.mode == TRUNET_PRO_BNBWD && (!sg.src1 || !sg.c0 || !sg.c1 || !sg.c2)) return false;
+    if (sg.mode == TRUNET_PRO_BNRELU && (!sg.c0 || !sg.c1)) return false;
+    if (sg.mode != TRUNET_PRO_NONE && sg.mode != TRUNET_PRO_BNRELU && sg.mode != TRUNET_PRO_BNBWD) return false;
+    return true;
+}
+
+extern "C" int trunet_bf16_gemm(const trunet_bgemm_args* h, void* stream) {
+    if (!h || !h->out || !h->wfrag || h->nseg < 1 || h->nseg > TRUNET_MAX_SEG) return TRUNET_EINVAL;
+    if (h->NP <= 0 || (h->NP % 64) != 0 || h->N <= 0 || h->N > h->NP || h->P <= 0 || h->M <= 0) return TRUNET_EINVAL;
+    if (h->M > 128 || h->nks_total <= 0 || h->nks_total > BG_MAXKS) return TRUNET_ENOTSUP;
+    if (h->out_L <= 0 || h->p_begin < 0 || h->p_begin + h->out_pos_off < 0 || h->p_begin + h->P + h->out_pos_off > h->out_L)
+        return TRUNET_EINVAL;
+    if ((h->epi & TRUNET_EPI_STATS) && (!h->partials || h->M_stat < h->M)) return TRUNET_EINVAL;
+    if ((h->epi & TRUNET_EPI_MASK) && (!h->zmask || !h->e0 || !h->e1)) return TRUNET_EINVAL;
+    if ((h->epi & TRUNET_EPI_BIAS) && !h->bias) return TRUNET_EINVAL;
+    for (int s = 0; s < h->nseg; ++s) {
+        const trunet_bseg& sg = h->seg[s];
+        if (!bseg_ok(sg) || sg.kstep0 < 0) return TRUNET_EINVAL;
+        if (sg.kstep0 + (((sg.nchan + 7) / 8 + 1) / 2) > h->nks_total) return TRUNET_EINVAL;
+    }
+    if (h->epi & TRUNET_EPI_STATS) {
+        if (hipMemsetAsync(h->partials, 0, (size_t)trunet_bf16_gemm_nparts() * h->M_stat * 2 * sizeof(float), ST) != hipSuccess)
+            return TRUNET_ELAUNCH;
+    }
+    const int nrt_all = (h->M + 31) / 32;
+    const size_t lds = (size_t)nrt_all * h->nks_total * 64 * 16 + (size_t)h->nks_total * 2 * 3 * 8 * sizeof(float) + 4 * 128 * sizeof(float);
+    if (nrt_all == 1) {
+        if (hipFuncSetAttribute((const void*)bgemm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return TRUNET_ELAUNCH;
+        hipLaunchKernelGGL(bgemm_kernel<1>, dim3(BG_GRID), dim3(256), lds, ST, *h);
+    } else {
+        if (hipFuncSetAttribute((const void*)bgemm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return TRUNET_ELAUNCH;
+        hipLaunchKernelGGL(bgemm_kernel<2>, dim3(BG_GRID), dim3(256), lds, ST, *h);
+    }
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_bf16_pack_weight(const float* W, void* wfrag, int M, int ldw_m, int ldw_c, int w_m_off, int nseg,
+                                       const int32_t* seg_nchan, const int32_t* seg_woff, void* stream) {
+    if (!W || !wfrag || M <= 0 || M > 128 || nseg < 1 || nseg > TRUNET_MAX_SEG || !seg_nchan || !seg_woff) return TRUNET_EINVAL;
+    PackDesc d;
+    int ks = 0;
+    for (int s = 0; s < TRUNET_MAX_SEG; ++s) {
+        d.nchan[s] = s < nseg ? seg_nchan[s] : 0;
+        d.woff[s] = s < nseg ? seg_woff[s] : 0;
+        d.ks0[s] = ks;
+        if (s < nseg) {
+            if (seg_nchan[s] <= 0) return TRUNET_EINVAL;
+            ks += ((seg_nchan[s] + 7) / 8 + 1) / 2;
+        }
+    }
+    if (ks > BG_MAXKS) return TRUNET_ENOTSUP;
+    d.nseg = nseg;
+    d.nks_total = ks;
+    const int total = ((M + 31) / 32) * ks * 64;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((total + 255) / 256), dim3(256), 0, ST, W, (u32x4*)wfrag, M, ldw_m, ldw_c,
+                       w_m_off, d);
+    const int rc = trunet_launch_status();
+    return rc == TRUNET_OK ? ks : rc;
+}
+
+extern "C" int trunet_bf16_wgrad(const trunet_bwgrad_args* h, void* stream) {
+    if (!h || !h->a0 || !h->w_partials || h->nseg < 1 || h->nseg > TRUNET_MAX_SEG) return TRUNET_EINVAL;
+    if (h->NP <= 0 || (h->NP % BW_F) != 0 || h->N <= 0 || h->N > h->NP || h->P <= 0 || h->M <= 0 || h->w_numel <= 0)
+        return TRUNET_EINVAL;
+    if (h->a_mode == TRUNET_PRO_BNBWD) { if (!h->a1 || !h->ac0 || !h->ac1 || !h->ac2) return TRUNET_EINVAL; }
+    else if (h->a_mode != TRUNET_PRO_NONE) return TRUNET_EINVAL;
+    if (h->a_L <= 0 || h->p_begin < 0 || h->p_begin + h->a_pos_off < 0 || h->p_begin + h->P + h->a_pos_off > h->a_L)
+        return TRUNET_EINVAL;
+    if (h->M > 128) return TRUNET_ENOTSUP;
+    int soct = 0, nct = 0;
+    for (int s = 0; s < h->nseg; ++s) {
+        const trunet_bseg& sg = h->seg[s];
+        if (!bseg_ok(sg) || sg.mode == TRUNET_PRO_BNBWD) return TRUNET_EINVAL;
+        // a 32-channel tile reads 4 octets: round every segment up to whole tiles in the LDS image
+        soct += ((sg.nchan + 31) / 32) * 4;
+        nct += (sg.nchan + 31) / 32;
+    }
+    if (soct > 8 * BW_MAXS || ((h->M + 31) / 32) * nct > 8 * BW_MAXT) return TRUNET_ENOTSUP;
+    const int moct = ((h->M + 31) / 32) * 4;
+    const size_t lds = 2 * (size_t)(moct + soct) * BW_OS;
+    if (hipFuncSetAttribute((const void*)bwgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return TRUNET_ELAUNCH;
+    hipLaunchKernelGGL(bwgrad_kernel, dim3(trunet_conv_wgrad_nparts()), dim3(BW_THREADS), lds, ST, *h, soct);
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_bf16_dw_nparts(int NP, int rows) { return (NP / 256) * bdw_chunks(rows); }
+
+extern "C" int trunet_bf16_dwconv_fwd(const void* zin, const float* s_in, const float* t_in, const float* w, const float* b,
+                                      void* zout, float* partials, int C, int K, int S, int Lin, int Lout, int NP, int N,
+                                      void* stream) {
+    if (!zin || !s_in || !t_in || !w || !b || !zout || !partials) return TRUNET_EINVAL;
+    if (C <= 0 || (C % 8) || NP <= 0 || (NP % 256) || N <= 0 || N > NP || Lin <= 0 || Lout != (Lin + 2 * (K / 2) - K) / S + 1)
+        return TRUNET_EINVAL;
+    const dim3 grid(NP / 256, C / 8, bdw_chunks(Lout));
+#define BDW_FWD(KK, SS) hipLaunchKernelGGL((bdw_fwd_kernel<KK, SS>), grid, dim3(256), 0, ST, (const u32x4*)zin, s_in, t_in, w, b, \
+                                           (u32x4*)zout, partials, C, Lin, Lout, NP, N)
+    if (K == 3 && S == 1) BDW_FWD(3, 1);
+    else if (K == 5 && S == 2) BDW_FWD(5, 2);
+    else if (K == 3 && S == 2) BDW_FWD(3, 2);
+    else return TRUNET_ENOTSUP;
+#undef BDW_FWD
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_bf16_dwconv_bwd(const void* dy, const void* z, const float* ca, const float* cb, const float* cc,
+                                      const void* zin, const float* s_in, const float* t_in, const float* mean_in,
+                                      const float* w, void* dy_in, float* partials_in, float* w_partials, float* b_partials,
+                                      int C, int K, int S, int Lin, int Lout, int NP, int N, void* stream) {
+    if (!dy || !z || !ca || !cb || !cc || !zin || !s_in || !t_in || !mean_in || !w || !dy_in || !partials_in || !w_partials ||
+        !b_partials)
+        return TRUNET_EINVAL;
+    if (C <= 0 || (C % 8) || NP <= 0 || (NP % 256) || N <= 0 || N > NP || Lin <= 0 || Lout != (Lin + 2 * (K / 2) - K) / S + 1)
+        return TRUNET_EINVAL;
+    const dim3 grid(NP / 256, C / 8, bdw_chunks(Lin));
+#define BDW_BWD(KK, SS) hipLaunchKernelGGL((bdw_bwd_kernel<KK, SS>), grid, dim3(256), 0, ST, (const u32x4*)dy, (const u32x4*)z, ca, \
+                                           cb, cc, (const u32x4*)zin, s_in, t_in, mean_in, w, (u32x4*)dy_in, partials_in,           \
+                                           w_partials, b_partials, C, Lin, Lout, NP, N)
+    if (K == 3 && S == 1) BDW_BWD(3, 1);
+    else if (K == 5 && S == 2) BDW_BWD(5, 2);
+    else if (K == 3 && S == 2) BDW_BWD(3, 2);
+    else return TRUNET_ENOTSUP;
+#undef BDW_BWD
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_bf16_from_frames_last(const float* x, void* y, int C, int L, int NP, void* stream) {
+    if (!x || !y || C <= 0 || L <= 0 || NP <= 0) return TRUNET_EINVAL;
+    const size_t R = (size_t)L * NP, total = (size_t)((C + 7) / 8) * R;
+    hipLaunchKernelGGL(from_fl_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ST, x, (u32x4*)y, C, R);
+    return trunet_launch_status();
+}
+extern "C" int trunet_bf16_to_frames_last(const void* x, float* y, int C, int L, int NP, void* stream) {
+    if (!x || !y || C <= 0 || L <= 0 || NP <= 0) return TRUNET_EINVAL;
+    const size_t R = (size_t)L * NP, total = (size_t)((C + 7) / 8) * R;
+    hipLaunchKernelGGL(to_fl_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ST, (const u32x4*)x, y, C, R);
+    return trunet_launch_status();
+}

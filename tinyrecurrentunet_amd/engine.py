@@ -133,21 +133,21 @@ class Workspace:
         self.t = {}
         self.gen = 0
 
-    def get(self, name, shape, zero=False):
+    def get(self, name, shape, zero=False, dtype=torch.float32):
         t = self.t.get(name)
-        if t is None or tuple(t.shape) != tuple(shape):
-            t = (torch.zeros if zero else torch.empty)(shape, device=self.dev, dtype=torch.float32)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = (torch.zeros if zero else torch.empty)(shape, device=self.dev, dtype=dtype)
             self.t[name] = t
         elif zero:
             t.zero_()
         return t
 
-    def flat(self, name, numel, zero=False):
+    def flat(self, name, numel, zero=False, dtype=torch.float32):
         """Grow-only 1-D scratch buffer (stream order makes sharing between layers safe); zero: zero-filled when it is
         (re)allocated, not per call."""
         t = self.t.get(name)
         if t is None or t.numel() < numel:
-            t = (torch.zeros if zero else torch.empty)(max(numel, 1), device=self.dev, dtype=torch.float32)
+            t = (torch.zeros if zero else torch.empty)(max(numel, 1), device=self.dev, dtype=dtype)
             self.t[name] = t
         return t
 

@@ -1,0 +1,410 @@
+"""bf16 schedule of the TRU-Net body (BASELINE.json configs[2]; a build extension -- the reference has no reduced
+precision path).
+
+Same layer schedule as ``engine.TRUNetEngine`` (``/root/reference/network.py:122-171`` with repairs R1-R4), on the
+``trunet_bf16_*`` kernels: every activation between layers and every activation gradient is stored as bf16 in the
+octet layout ``[C/8][L][NP][8]`` and multiplied on ``v_mfma_f32_32x32x16_bf16``; accumulators, BatchNorm statistics and
+coefficients, weight gradients (the flat fp32 gradient tensor of the fp32 engine, so the all-reduce and FusedAdamW are
+unchanged) and the master weights stay fp32.  The frequency-recurrent bottleneck (FGRU: 16 positions, 1.5 % of the
+activation bytes) runs on the fp32 kernels between two layout conversions.
+
+What is not offered in bf16: the TGRU block and the stand-alone block classes (fp32 only).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from . import engine as E
+from ._lib import (EPI_ACCUM, EPI_BIAS, EPI_MASK, EPI_RELU, EPI_STATS, PRO_BNBWD, PRO_BNRELU, PRO_NONE, BGemmArgs, BSeg,
+                   BWgradArgs, check, ptr, ptr16)
+from .engine import BN_MOM, F_BINS, FRAME_PAD, Act, TRUNetEngine, _Timed, _seg_positions, ceil_to
+
+BF16 = torch.bfloat16
+
+
+def bseg(src0, nchan, Ln, pos_mul=1, pos_off=0, pos_div=1, woff=0, mode=PRO_NONE, src1=None, c0=None, c1=None, c2=None):
+    s = BSeg()
+    s.src0, s.src1 = ptr16(src0), ptr16(src1)
+    s.c0, s.c1, s.c2 = ptr(c0), ptr(c1), ptr(c2)
+    s.nchan, s.L = nchan, Ln
+    s.pos_mul, s.pos_off, s.pos_div = pos_mul, pos_off, pos_div
+    s.woff, s.mode, s.kstep0 = woff, mode, 0
+    return s
+
+
+class Act16:
+    """A bf16 activation in the octet layout [ceil(C/8)][L][NP][8] and how a consumer must read it."""
+
+    def __init__(self, t, Cn, Ln, bn=None):
+        self.t, self.C, self.L, self.bn = t, Cn, Ln, bn
+
+    def seg(self, pos_off=0, woff=0, pos_mul=1, pos_div=1):
+        if self.bn is None:
+            return bseg(self.t, self.C, self.L, pos_mul, pos_off, pos_div, woff, PRO_NONE)
+        return bseg(self.t, self.C, self.L, pos_mul, pos_off, pos_div, woff, PRO_BNRELU, c0=self.bn.scale,
+                    c1=self.bn.shift)
+
+
+def _oct(Cn):
+    return (Cn + 7) // 8
+
+
+def _ksteps(nchan):
+    return (_oct(nchan) + 1) // 2
+
+
+class TRUNetEngineBF16(TRUNetEngine):
+    """TRUNetEngine with bf16 activation storage (see the module docstring)."""
+
+    # ------------------------------------------------------------------ launches
+    def _get16(self, w, name, Cn, Ln, NP):
+        return w.get(name, (_oct(Cn), Ln, NP, 8), dtype=BF16)
+
+    def _gemm16(self, w, *, N, NP, P, M, out, out_L, W, ldw_m, ldw_c, segs, p_begin=0, out_pos_off=0, w_m_off=0, epi=0,
+                bias=None, zmask=None, e0=None, e1=None, e2=None, stats=None):
+        """trunet_bf16_gemm: out[m][p + out_pos_off] = epi(sum_seg W_seg . pro(src_seg)); the fp32 weight is packed into
+        MFMA A fragments first (trunet_bf16_pack_weight, a few microseconds)."""
+        lib, st = L.lib(), L.stream()
+        nseg = len(segs)
+        nchan = (C.c_int32 * nseg)(*[s.nchan for s in segs])
+        woff = (C.c_int32 * nseg)(*[s.woff for s in segs])
+        nks = sum(_ksteps(s.nchan) for s in segs)
+        wfrag = w.flat("wfrag", ((M + 31) // 32) * nks * 64 * 8, dtype=BF16)
+        rc = lib.trunet_bf16_pack_weight(ptr(W), ptr16(wfrag), M, ldw_m, ldw_c, w_m_off, nseg, nchan, woff, st)
+        if rc != nks:
+            raise L.TrunetHipError("trunet_bf16_pack_weight: code %d (expected %d k-steps)" % (rc, nks))
+        a = BGemmArgs()
+        a.NP, a.N, a.P, a.p_begin = NP, N, P, p_begin
+        a.M, a.out_L, a.out_pos_off, a.nseg, a.nks_total = M, out_L, out_pos_off, nseg, nks
+        k0 = 0
+        for i, s in enumerate(segs):
+            s.kstep0 = k0
+            k0 += _ksteps(s.nchan)
+            a.seg[i] = s
+        a.out, a.wfrag = ptr16(out), ptr16(wfrag)
+        if bias is not None:
+            epi |= EPI_BIAS
+            a.bias = ptr(bias)
+        if zmask is not None:
+            epi |= EPI_MASK
+            a.zmask, a.e0, a.e1, a.e2 = ptr16(zmask), ptr(e0), ptr(e1), ptr(e2)
+        nparts = 0
+        if stats is not None:
+            epi |= EPI_STATS
+            nparts = lib.trunet_bf16_gemm_nparts()
+            part = w.flat("partials", nparts * stats * 2)
+            a.partials, a.M_stat = ptr(part), stats
+        a.epi = epi
+        if E.PROFILE is not None:
+            # algorithmic bytes: every valid source row read once (twice for a BatchNorm-backward pair), the output row
+            # written once (+ read for accumulate / mask), 2 bytes per element over the N valid frames
+            by = 0
+            for s in segs:
+                by += 2 * s.nchan * _seg_positions(s, p_begin, P) * (2 if s.mode == PRO_BNBWD else 1)
+            by += 2 * M * P * (1 + (1 if epi & EPI_ACCUM else 0) + (1 if epi & EPI_MASK else 0))
+            tag = "M%d K%s P%d" % (M, "+".join(str(s.nchan) for s in segs), P)
+            with _Timed("bgemm_kernel<%d>" % (1 if M <= 32 else 2), float(by) * N, tag):
+                check(lib.trunet_bf16_gemm(a, st), "bf16_gemm")
+            return nparts
+        check(lib.trunet_bf16_gemm(a, st), "bf16_gemm")
+        return nparts
+
+    def _wgrad16(self, w, *, N, NP, P, M, dz, dz_L, dz_bn, W, ldw_m, ldw_c, segs, grads, bias=None, a_pos_off=0,
+                 w_m_off=0, b_off=0, dz1=None):
+        lib = L.lib()
+        a = BWgradArgs()
+        a.NP, a.N, a.P, a.p_begin = NP, N, P, 0
+        a.M, a.a_L, a.a_pos_off = M, dz_L, a_pos_off
+        a.ldw_m, a.ldw_c, a.w_m_off = ldw_m, ldw_c, w_m_off
+        a.nseg = len(segs)
+        for i, s in enumerate(segs):
+            a.seg[i] = s
+        a.a0 = ptr16(dz)
+        if dz_bn is not None:
+            a.a_mode = PRO_BNBWD
+            a.a1, a.ac0, a.ac1, a.ac2 = ptr16(dz1), ptr(dz_bn.ca), ptr(dz_bn.cb), ptr(dz_bn.cc)
+        else:
+            a.a_mode = PRO_NONE
+        a.w_numel = self._wg_total
+        a.w_partials = self._wg_slot(W)
+        if bias is not None:
+            a.b_partials = self._wg_slot(bias)
+            a.b_stride, a.b_off = self._wg_total, b_off
+        if E.PROFILE is not None:
+            by = 2 * M * P * (2 if dz_bn is not None else 1) + sum(2 * s.nchan * _seg_positions(s, 0, P) for s in segs)
+            with _Timed("bwgrad_kernel", float(by) * N, "M%d K%s P%d" % (M, "+".join(str(s.nchan) for s in segs), P)):
+                check(lib.trunet_bf16_wgrad(a, L.stream()), "bf16_wgrad")
+        else:
+            check(lib.trunet_bf16_wgrad(a, L.stream()), "bf16_wgrad")
+
+    # ------------------------------------------------------------------ forward layers
+    def _pw(self, w, name, srcs, conv, bn, N, NP, training, x1_left=0):
+        Ln = srcs[-1].L
+        Co, K = conv.out_channels, conv.in_channels
+        out = self._get16(w, "z:" + name, Co, Ln, NP)
+        segs, off = [], 0
+        for i, s in enumerate(srcs):
+            segs.append(s.seg(pos_off=(-x1_left if (i == 0 and len(srcs) == 2) else 0), woff=off))
+            off += s.C
+        assert off == K
+        nparts = self._gemm16(w, N=N, NP=NP, P=Ln, M=Co, out=out, out_L=Ln, W=conv.weight.data, ldw_m=K, ldw_c=1,
+                              segs=segs, bias=conv.bias.data, stats=(Co if (bn is not None and training) else None))
+        st = self._bn_fwd(w, name, bn, Co, N * Ln, nparts, training) if bn is not None else None
+        return Act16(out, Co, Ln, st)
+
+    def _convT(self, w, name, src, conv, bn, N, NP, training):
+        k, s, pad = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        Co = conv.out_channels
+        Lo = (src.L - 1) * s - 2 * pad + k
+        out = self._get16(w, "z:" + name, Co, Lo, NP)
+        segs = [src.seg(pos_off=pad - kk, woff=kk, pos_div=s) for kk in range(k)]
+        nparts = self._gemm16(w, N=N, NP=NP, P=Lo, M=Co, out=out, out_L=Lo, W=conv.weight.data, ldw_m=k, ldw_c=Co * k,
+                              segs=segs, bias=conv.bias.data, stats=(Co if (bn is not None and training) else None))
+        st = self._bn_fwd(w, name, bn, Co, N * Lo, nparts, training) if bn is not None else None
+        return Act16(out, Co, Lo, st)
+
+    def _dw(self, w, name, src, conv, bn, N, NP, training):
+        k, s = conv.kernel_size[0], conv.stride[0]
+        Cn = conv.out_channels
+        Lo = (src.L + 2 * (k // 2) - k) // s + 1
+        out = self._get16(w, "z:" + name, Cn, Lo, NP)
+        lib = L.lib()
+        nparts = lib.trunet_bf16_dw_nparts(NP, Lo)
+        part = w.flat("partials_dw", nparts * Cn * 2)
+        if E.PROFILE is not None:
+            with _Timed("bdw_fwd_kernel<%d, %d>" % (k, s), 2.0 * Cn * (src.L + Lo) * N, "L%d" % Lo):
+                check(lib.trunet_bf16_dwconv_fwd(ptr16(src.t), ptr(src.bn.scale), ptr(src.bn.shift), ptr(conv.weight.data),
+                                                 ptr(conv.bias.data), ptr16(out), ptr(part), Cn, k, s, src.L, Lo, NP, N,
+                                                 L.stream()), "bf16_dwconv_fwd")
+        else:
+            check(lib.trunet_bf16_dwconv_fwd(ptr16(src.t), ptr(src.bn.scale), ptr(src.bn.shift), ptr(conv.weight.data),
+                                             ptr(conv.bias.data), ptr16(out), ptr(part), Cn, k, s, src.L, Lo, NP, N,
+                                             L.stream()), "bf16_dwconv_fwd")
+        st = w.bn(name, Cn)
+        st.module, st.count = bn, float(N * Lo)
+        if training:
+            rm = bn.running_mean if bn.track_running_stats else None
+            rv = bn.running_var if bn.track_running_stats else None
+            mom = BN_MOM if bn.momentum is None else bn.momentum
+            nbt = bn.num_batches_tracked.data_ptr() if bn.track_running_stats else None
+            check(lib.trunet_bn_finalize_fwd(ptr(part), nparts, Cn, float(N * Lo), ptr(bn.weight.data), ptr(bn.bias.data),
+                                             bn.eps, mom, ptr(rm), ptr(rv), ptr(st.scale), ptr(st.shift), ptr(st.mean),
+                                             ptr(st.rstd), nbt, L.stream()), "bn_finalize_fwd")
+        else:
+            check(lib.trunet_bn_eval_affine(Cn, ptr(bn.weight.data), ptr(bn.bias.data), ptr(bn.running_mean),
+                                            ptr(bn.running_var), bn.eps, ptr(st.scale), ptr(st.shift), L.stream()),
+                  "bn_eval_affine")
+        return Act16(out, Cn, Lo, st)
+
+    def _to16(self, w, name, t32, Cn, Ln, NP):
+        t16 = self._get16(w, name, Cn, Ln, NP)
+        check(L.lib().trunet_bf16_from_frames_last(ptr(t32), ptr16(t16), Cn, Ln, NP, L.stream()), "bf16_from_frames_last")
+        return t16
+
+    def _to32(self, w, name, t16, Cn, Ln, NP):
+        t32 = w.get(name, (Cn, Ln, NP))
+        check(L.lib().trunet_bf16_to_frames_last(ptr16(t16), ptr(t32), Cn, Ln, NP, L.stream()), "bf16_to_frames_last")
+        return t32
+
+    # ------------------------------------------------------------------ stand-alone blocks: fp32 only
+    def block_forward(self, *a, **k):
+        raise L.TrunetHipError("the stand-alone block classes run in fp32 only")
+
+    gru_block_forward = block_forward
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, training, tgru_state=None, tgru_T=None, record=False):
+        if tgru_state is not None or tgru_T is not None:
+            raise L.TrunetHipError("the TGRU block is not part of the bf16 schedule (fp32 only)")
+        net = self.net
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[2] == F_BINS
+        x = x.contiguous()
+        N, Cin = x.shape[0], x.shape[1]
+        NP = ceil_to(N, FRAME_PAD)
+        w = self.ws(NP, x.device, record)
+        if record:
+            w.gen += 1
+        lib, st = L.lib(), L.stream()
+        acts = {}
+
+        xt = w.get("x", (Cin, F_BINS, NP))
+        check(lib.trunet_to_frames_last(ptr(x), ptr(xt), N, Cin, F_BINS, NP, st), "to_frames_last")
+        x16 = Act16(self._to16(w, "x16", xt, Cin, F_BINS, NP), Cin, F_BINS)
+        acts["x"] = x16
+        # first conv (network.py:13): one segment per tap of the strided input, bias + ReLU in the epilogue
+        c0 = net.encoder[0].StandardConv1d[0]
+        k, s_, pad = c0.kernel_size[0], c0.stride[0], c0.padding[0]
+        assert c0.in_channels == Cin
+        L0 = (F_BINS + 2 * pad - k) // s_ + 1
+        a0 = self._get16(w, "z:enc0", c0.out_channels, L0, NP)
+        self._gemm16(w, N=N, NP=NP, P=L0, M=c0.out_channels, out=a0, out_L=L0, W=c0.weight.data, ldw_m=Cin * k, ldw_c=k,
+                     segs=[x16.seg(pos_mul=s_, pos_off=kk - pad, woff=kk) for kk in range(k)], bias=c0.bias.data,
+                     epi=EPI_RELU)
+        cur = acts["enc0"] = Act16(a0, c0.out_channels, L0)
+        for i in range(1, 6):
+            seq = net.encoder[i].DepthwiseSeparableConv1d
+            cur = acts["enc%d.pw" % i] = self._pw(w, "enc%d.pw" % i, [cur], seq[0], seq[1], N, NP, training)
+            cur = acts["enc%d" % i] = self._dw(w, "enc%d" % i, cur, seq[3], seq[4], N, NP, training)
+
+        # FGRU in fp32 between two layout conversions
+        enc5f = acts["enc5.f32"] = Act(self._to32(w, "z:enc5.f32", cur.t, cur.C, cur.L, NP), cur.C, cur.L, cur.bn)
+        acts["hout"] = self._gru(w, enc5f, net.FGRU.GRU, N, NP, training)
+        fg = acts["fgru.f32"] = TRUNetEngine._pw(self, w, "fgru", [acts["hout"]], net.FGRU.conv[0], net.FGRU.conv[1], N, NP,
+                                                 training)
+        cur = acts["fgru"] = Act16(self._to16(w, "z:fgru16", fg.t, fg.C, fg.L, NP), fg.C, fg.L, fg.bn)
+
+        seq = net.decoder[0].FirstTrCNN
+        cur = acts["dec0.pw"] = self._pw(w, "dec0.pw", [cur], seq[0], seq[1], N, NP, training)
+        cur = acts["dec0"] = self._convT(w, "dec0", cur, seq[3], seq[4], N, NP, training)
+        for i in range(1, 6):
+            skip = acts["enc%d" % (5 - i)]
+            seq = net.decoder[i].TrCNN if i < 5 else net.decoder[i].LastTrCNN
+            left = (skip.L - cur.L) // 2
+            cur = acts["dec%d.pw" % i] = self._pw(w, "dec%d.pw" % i, [cur, skip], seq[0], seq[1], N, NP, training,
+                                                  x1_left=left)
+            cur = acts["dec%d" % i] = self._convT(w, "dec%d" % i, cur, seq[3], seq[4] if i < 5 else None, N, NP, training)
+        o32 = self._to32(w, "out.f32", cur.t, cur.C, cur.L, NP)
+        out = torch.empty((N, cur.C, cur.L), device=x.device, dtype=torch.float32)
+        check(lib.trunet_from_frames_last(ptr(o32), ptr(out), N, cur.C, cur.L, NP, st), "from_frames_last")
+        return out, (acts, N, NP, w, w.gen)
+
+    # ------------------------------------------------------------------ backward pieces
+    @staticmethod
+    def _dz_seg16(dy_, z_, bn_, Cn, Ln, **kw):
+        if bn_ is None:
+            return bseg(dy_, Cn, Ln, mode=PRO_NONE, **kw)
+        return bseg(dy_, Cn, Ln, mode=PRO_BNBWD, src1=z_, c0=bn_.ca, c1=bn_.cb, c2=bn_.cc, **kw)
+
+    def _pw_bwd16(self, w, *, N, NP, P, M, dz, dz1, dz_bn, W, bias, segs, outs, grads):
+        """Backward of a Conv1d(k=1)+BatchNorm layer: one weight-gradient launch, one data-gradient launch per source
+        (ReLU mask / skip accumulation / BatchNorm-backward statistics in its epilogue)."""
+        K = sum(s.nchan for s in segs)
+        self._wgrad16(w, N=N, NP=NP, P=P, M=M, dz=dz, dz1=dz1, dz_L=P, dz_bn=dz_bn, W=W, ldw_m=K, ldw_c=1, segs=segs,
+                      grads=grads, bias=bias)
+        for sg, o in zip(segs, outs):
+            src = o.get("src")
+            p0, p1 = max(0, -sg.pos_off), min(P, sg.L - sg.pos_off)
+            kw = {}
+            if src is not None:
+                if src.bn is not None:
+                    kw = dict(zmask=src.t, e0=src.bn.scale, e1=src.bn.shift, e2=src.bn.mean, stats=sg.nchan)
+                else:       # ReLU-only source (enc0): mask = z > 0
+                    one = w.get("ones%d" % sg.nchan, (sg.nchan,))
+                    zero = w.get("zeros%d" % sg.nchan, (sg.nchan,))
+                    one.fill_(1.0)
+                    zero.zero_()
+                    kw = dict(zmask=src.t, e0=one, e1=zero, e2=zero)
+            nparts = self._gemm16(w, N=N, NP=NP, P=p1 - p0, p_begin=p0, M=sg.nchan, out=o["out"], out_L=sg.L,
+                                  out_pos_off=sg.pos_off, W=W.data, ldw_m=1, ldw_c=K, w_m_off=sg.woff,
+                                  segs=[self._dz_seg16(dz, dz1, dz_bn, M, P)], epi=(EPI_ACCUM if o.get("accum") else 0),
+                                  **kw)
+            if src is not None and src.bn is not None:
+                self._bn_bwd(w, src.bn, nparts, grads)
+
+    def _bwd_tr16(self, w, N, NP, ct, pw, a_pw, Lo, up, x1, x1_mask, skip, left, dy_x1, g_skip, dy_pw_name, grads):
+        """FirstTrCNN / TrCNN / LastTrCNN (network.py:60-120): transposed conv, then the pointwise conv over [x1 | skip]"""
+        dy, z, bn = up
+        k, s_, pad = ct.kernel_size[0], ct.stride[0], ct.padding[0]
+        Ci, Co = ct.in_channels, ct.out_channels
+        dy_pw = self._get16(w, dy_pw_name, Ci, a_pw.L, NP)
+        self._wgrad16(w, N=N, NP=NP, P=Lo, M=Co, dz=dy, dz1=z, dz_L=Lo, dz_bn=bn, W=ct.weight, ldw_m=k, ldw_c=Co * k,
+                      segs=[a_pw.seg(pos_off=pad - kk, woff=kk, pos_div=s_) for kk in range(k)], grads=grads, bias=ct.bias)
+        segs = [self._dz_seg16(dy, z, bn, Co, Lo, pos_mul=s_, pos_off=kk - pad, woff=kk) for kk in range(k)]
+        nparts = self._gemm16(w, N=N, NP=NP, P=a_pw.L, M=Ci, out=dy_pw, out_L=a_pw.L, W=ct.weight.data, ldw_m=Co * k,
+                              ldw_c=k, segs=segs, zmask=a_pw.t, e0=a_pw.bn.scale, e1=a_pw.bn.shift, e2=a_pw.bn.mean,
+                              stats=Ci)
+        self._bn_bwd(w, a_pw.bn, nparts, grads)
+        Lp = a_pw.L
+        srcs = [x1.seg(pos_off=-left, woff=0)] + ([skip.seg(woff=x1.C)] if skip is not None else [])
+        p0, p1 = max(0, left), min(Lp, x1.L + left)
+        if p1 - p0 < x1.L:          # cropped positions of x1 (network.py:96-97 with a negative pad) get no gradient
+            q0, q1 = p0 - left, p1 - left
+            if q0 > 0:
+                dy_x1[:, :q0].zero_()
+            if q1 < x1.L:
+                dy_x1[:, q1:].zero_()
+        outs = [dict(out=dy_x1, src=x1_mask)] + ([dict(out=g_skip)] if skip is not None else [])
+        self._pw_bwd16(w, N=N, NP=NP, P=Lp, M=pw.out_channels, dz=dy_pw, dz1=a_pw.t, dz_bn=a_pw.bn, W=pw.weight,
+                       bias=pw.bias, segs=srcs, outs=outs, grads=grads)
+
+    def _bwd_dsc16(self, w, N, NP, seq, a_pw, a_dw, up, prev, prev_mask, accum, dy_prev, dy_pw_name, grads):
+        """DepthwiseSeparableConv1d (network.py:24-43): depthwise conv (fused dgrad + wgrad + BN-backward sums), then the
+        pointwise conv; dy_prev receives the gradient of the block input (added to the skip gradient when ``accum``)."""
+        lib, st = L.lib(), L.stream()
+        dy, z, bn = up
+        pw, dwc = seq[0], seq[3]
+        k, s_ = dwc.kernel_size[0], dwc.stride[0]
+        Cn = dwc.out_channels
+        dy_pw = self._get16(w, dy_pw_name, Cn, a_pw.L, NP)
+        nparts = lib.trunet_bf16_dw_nparts(NP, a_pw.L)
+        part = w.flat("partials_dw", nparts * Cn * 2)
+        wpart = w.flat("dw_w_partials", nparts * Cn * k)
+        bpart = w.flat("dw_b_partials", nparts * Cn)
+        args = (ptr16(dy), ptr16(z), ptr(bn.ca), ptr(bn.cb), ptr(bn.cc), ptr16(a_pw.t), ptr(a_pw.bn.scale),
+                ptr(a_pw.bn.shift), ptr(a_pw.bn.mean), ptr(dwc.weight.data), ptr16(dy_pw), ptr(part), ptr(wpart), ptr(bpart),
+                Cn, k, s_, a_pw.L, a_dw.L, NP, N, st)
+        if E.PROFILE is not None:
+            with _Timed("bdw_bwd_kernel<%d, %d>" % (k, s_), 2.0 * Cn * (2 * a_dw.L + 2 * a_pw.L) * N, "L%d" % a_pw.L):
+                check(lib.trunet_bf16_dwconv_bwd(*args), "bf16_dwconv_bwd")
+        else:
+            check(lib.trunet_bf16_dwconv_bwd(*args), "bf16_dwconv_bwd")
+        check(lib.trunet_reduce_partials(self._wg_slot(dwc.weight), ptr(wpart), nparts, Cn * k, 0, st), "reduce")
+        check(lib.trunet_reduce_partials(self._wg_slot(dwc.bias), ptr(bpart), nparts, Cn, 0, st), "reduce")
+        self._bn_bwd(w, a_pw.bn, nparts, grads, part_name="partials_dw")
+        self._pw_bwd16(w, N=N, NP=NP, P=a_pw.L, M=pw.out_channels, dz=dy_pw, dz1=a_pw.t, dz_bn=a_pw.bn, W=pw.weight,
+                       bias=pw.bias, segs=[prev.seg()], outs=[dict(out=dy_prev, src=prev_mask, accum=accum)], grads=grads)
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, ctx, gout):
+        acts, N, NP, w, gen = ctx
+        self._check_gen(w, gen)
+        net = self.net
+        lib, st = L.lib(), L.stream()
+        grads = {}
+        self._wg_begin(w)
+        gout = gout.contiguous()
+        last = acts["dec5"]
+        g32 = w.get("dy:dec5.f32", (last.C, last.L, NP))
+        check(lib.trunet_to_frames_last(ptr(gout), ptr(g32), N, last.C, last.L, NP, st), "to_frames_last")
+        dyt = self._to16(w, "dy:dec5", g32, last.C, last.L, NP)
+        up = (dyt, last.t, None)
+        for i in range(5, -1, -1):
+            seq = (net.decoder[i].LastTrCNN if i == 5 else net.decoder[i].TrCNN) if i > 0 else net.decoder[0].FirstTrCNN
+            if i > 0:
+                x1, x1n = acts["dec%d" % (i - 1)], "dec%d" % (i - 1)
+                skip = acts["enc%d" % (5 - i)]
+                left = (skip.L - x1.L) // 2
+                g_skip = self._get16(w, "dy:enc%d" % (5 - i), skip.C, skip.L, NP)
+            else:
+                x1n = "fgru"
+                x1, skip, left, g_skip = acts[x1n], None, 0, None
+            dy_x1 = self._get16(w, "dy:" + x1n, x1.C, x1.L, NP)
+            self._bwd_tr16(w, N, NP, seq[3], seq[0], acts["dec%d.pw" % i], acts["dec%d" % i].L, up, x1, x1, skip, left,
+                           dy_x1, g_skip, "dy:dec%d.pw" % i, grads)
+            up = (dy_x1, x1.t, x1.bn)
+
+        # -------- FGRU (fp32)
+        fg, enc5f, enc5 = acts["fgru.f32"], acts["enc5.f32"], acts["enc5"]
+        dyf = self._to32(w, "dy:fgru.f32", up[0], fg.C, fg.L, NP)
+        dy5f = w.get("dy:enc5.f32", (enc5f.C, enc5f.L, NP))
+        self._bwd_fgru(w, N, NP, net.FGRU, (dyf, fg.t, fg.bn), acts["hout"], enc5f, enc5f, dy5f, grads)
+        dy5 = self._to16(w, "dy:enc5", dy5f, enc5.C, enc5.L, NP)
+        up = (dy5, enc5.t, enc5.bn)
+
+        for i in range(5, 0, -1):
+            prev = acts["enc%d" % (i - 1)]
+            dy_prev = self._get16(w, "dy:enc%d" % (i - 1), prev.C, prev.L, NP)
+            self._bwd_dsc16(w, N, NP, net.encoder[i].DepthwiseSeparableConv1d, acts["enc%d.pw" % i], acts["enc%d" % i], up,
+                            prev, prev, True, dy_prev, "dy:enc%d.pw" % i, grads)
+            up = (dy_prev, prev.t, prev.bn)
+
+        # -------- first conv (its output is ReLU-only: up[0] is already masked)
+        c0 = net.encoder[0].StandardConv1d[0]
+        xa = acts["x"]
+        k, s_, pad = c0.kernel_size[0], c0.stride[0], c0.padding[0]
+        self._wgrad16(w, N=N, NP=NP, P=acts["enc0"].L, M=c0.out_channels, dz=up[0], dz_L=acts["enc0"].L, dz_bn=None,
+                      W=c0.weight, ldw_m=xa.C * k, ldw_c=k,
+                      segs=[xa.seg(pos_mul=s_, pos_off=kk - pad, woff=kk) for kk in range(k)], grads=grads, bias=c0.bias)
+        self._wg_finish(grads)
+        return grads

@@ -185,8 +185,12 @@ class TRUNet(nn.Module):
     registered for checkpoint parity and not executed (R4)."""
 
     def __init__(self, input_size=3, channels_input=64, channels_output=3, channels_hidden=128,
-                 kernel_sizes=(5, 3), strides=(2, 1), tr_channels_input=192, use_tgru=False):
+                 kernel_sizes=(5, 3), strides=(2, 1), tr_channels_input=192, use_tgru=False, precision="fp32"):
         super().__init__()
+        # precision (extension; BASELINE.json configs[2]): "bf16" stores activations and their gradients as bf16 and
+        # multiplies on the bf16 MFMA (engine_bf16.py); parameters, BatchNorm statistics, gradients of parameters stay fp32
+        self.precision = "fp32"
+        self.set_precision(precision)
         # use_tgru (extension, default = the reference as written, R4): run the TGRU block over time between FGRU and
         # the decoder as drawn in docs/net.jpg; forward then needs frames_per_seq = T (N = B*T frames)
         self.use_tgru = bool(use_tgru)
@@ -208,6 +212,24 @@ class TRUNet(nn.Module):
         self.TGRU = GRUBlock(64, 128, 64, bidirectional=False)
         object.__setattr__(self, "_engine", None)
 
+    def set_precision(self, precision):
+        """"fp32" (the reference's precision, default) or "bf16" (activation storage + MFMA operands; training forward /
+        backward of the full network only -- eval forwards take the folded fp32 single-launch path as before)."""
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16', got %r" % (precision,))
+        if precision == "bf16" and self.__dict__.get("use_tgru", False):
+            raise _lib.TrunetHipError("use_tgru is fp32 only")
+        if precision != self.precision:
+            object.__setattr__(self, "_engine", None)
+        self.precision = precision
+        return self
+
+    def _make_engine(self):
+        if self.precision == "bf16":
+            from .engine_bf16 import TRUNetEngineBF16
+            return TRUNetEngineBF16(self)
+        return TRUNetEngine(self)
+
     def stream_step(self, x, state=None):
         """Stateful causal streaming with the time-recurrent block: ``x`` (streams, C_in, 257) is ONE
         new STFT frame per stream; the encoder, FGRU and decoder run as in ``forward`` (eval mode) and the TGRU block
@@ -217,6 +239,8 @@ class TRUNet(nn.Module):
         _need_gpu(x)
         if self.training:
             raise _lib.TrunetHipError("stream_step is an inference path: call net.eval() first")
+        if self.precision != "fp32":
+            raise _lib.TrunetHipError("stream_step is fp32 only")
         if self._engine is None:
             object.__setattr__(self, "_engine", TRUNetEngine(self))
         if state is None:
@@ -231,7 +255,7 @@ class TRUNet(nn.Module):
     def forward(self, x, frames_per_seq=None):
         _need_gpu(x)
         if self._engine is None:
-            object.__setattr__(self, "_engine", TRUNetEngine(self))
+            object.__setattr__(self, "_engine", self._make_engine())
         T = None
         if self.use_tgru:
             if frames_per_seq is None:
