@@ -26,6 +26,7 @@ STFT_CFG = dict(fft_sizes=[512, 1024, 2048], hop_sizes=[50, 120, 240], win_lengt
 FLOPS_PER_FRAME_STEP = 94089216       # 3 x 31,363,072 (C_in = 4)
 PEAK_F32_TFLOPS = 157.3               # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
 HBM_BYTES_PER_FRAME_STEP = 2462912    # SURVEY 8d (ii) layer-boundary model
+PEAK_HBM_GBPS = 8000.0                # MI355X_MICROARCH.md: HBM3E
 
 
 def synth(B, L, seed, device):
@@ -221,9 +222,8 @@ def main():
     ap.add_argument("--streaming", action="store_true",
                     help="BASELINE.json configs[3]: 1-frame causal forward of 1024 concurrent streams (rt.py protocol)")
     args = ap.parse_args()
-    if args.dtype != "f32":
-        raise SystemExit("bench.py --dtype bf16: the bf16 storage / MFMA family (BASELINE.json configs[2]) is not built "
-                         "(DESIGN.md section 7); every kernel computes fp32, which is configs[1], the headline metric")
+    if args.dtype == "bf16" and (args.tgru or args.streaming):
+        raise SystemExit("bench.py --dtype bf16: the TGRU block and the streaming forward are fp32 only")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -251,7 +251,8 @@ def main():
         return streaming(args, dev)
     cin = 3 if args.no_pcen else 4
     torch.manual_seed(0)                      # train.py:12-14
-    net = hn.TRUNet(input_size=cin, use_tgru=args.tgru).to(dev).train()      # --tgru: extension, not the headline config
+    net = hn.TRUNet(input_size=cin, use_tgru=args.tgru,
+                    precision=("bf16" if args.dtype == "bf16" else "fp32")).to(dev).train()      # --tgru: extension
     if use_dist:
         tdist.apply_gradient_allreduce(net)
     opt = optim.FusedAdamW(net.parameters(), lr=4e-4)
@@ -343,7 +344,28 @@ def main():
                         break
         except Exception:
             traffic = None
-        roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS,
+        # rank the bf16 family by kernel (all template instances of one kernel together), report the dominant instance
+        if args.dtype == "bf16":
+            fam = {}
+            for k, v in agg.items():
+                fam.setdefault(k.split("<")[0], []).append((v[0], k))
+            top = max(fam.values(), key=lambda l: sum(t for t, _ in l))
+            name = max(top)[1]
+            tot_ms, flops, n = agg[name]
+        bf16_kernel = name.startswith(("bgemm_kernel", "bwgrad_kernel", "bdw_"))
+        if bf16_kernel:
+            # the bf16 family is an HBM stream: `flops` holds the ALGORITHMIC BYTES of its launches (every operand row
+            # read once, every output row written once, 2 B per element, valid frames only: engine_bf16.py)
+            gbs = flops / (tot_ms * 1e-3) / 1e9
+            bytes_per_frame = HBM_BYTES_PER_FRAME_STEP / 2
+            roof = {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                    "frac": round(gbs / PEAK_HBM_GBPS, 4), "traffic": None, "launches_per_step": n,
+                    "avg_launch_ms": round(tot_ms / n, 4), "algorithmic_bytes_per_launch": round(flops / n),
+                    "kernel_ms_per_step": {k: round(v[0], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])},
+                    "step_hbm_GBps_layer_model": round(value / world * bytes_per_frame / 1e9, 1),
+                    "step_hbm_frac_layer_model": round(value / world * bytes_per_frame / 1e9 / PEAK_HBM_GBPS, 4)}
+        else:
+          roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": traffic,
                 "traffic_GBps": (round(traffic / (tot_ms / n * 1e-3) / 1e9, 1) if traffic else None),
                 "traffic_source": traffic_src, "traffic_measured_on_other_kernel_source": traffic_stale,
@@ -357,11 +379,13 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                "ms_per_step_median": round(pctl(step_ms, 0.5), 3), "ms_per_step_p10": round(pctl(step_ms, 0.1), 3),
                "ms_per_step_p90": round(pctl(step_ms, 0.9), 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
                "data": "synthetic",
                "config": {"workload": "config/tiny.json TRU-Net (C_in=%d%s), %d x %.0f s 16 kHz pairs per GPU, "
-                                      "n_fft 512 hop 128, full fp32 train step%s" % (
+                                      "n_fft 512 hop 128, full %s train step%s" % (
                                           cin, " incl. PCEN" if cin == 4 else "", args.batch, args.seconds,
+                                          "fp32" if args.dtype == "f32" else
+                                          "bf16-storage (bf16 MFMA, fp32 accumulate / statistics / master weights)",
                                           ("" if stft_lambda else " WITHOUT MR-STFT loss") +
                                           (" WITH the TGRU block trained over time (use_tgru extension)" if args.tgru else "")),
                           "frames_per_gpu": frames, "global_batch": args.batch * world,

@@ -324,7 +324,7 @@ def test_bf16_wgrad_shapes_of_the_backward():
     M, P = 8, 6
     dz, z = _rb(rnd(M, P, NP)), _rb(rnd(M, P, NP))
     segs = [dict(x=_rb(rnd(64, 6, NP)), mode=1, c0=rnd(64) * 0.3 + 1, c1=rnd(64) * 0.2, woff=0),
-            dict(x=_rb(rnd(64, 6, NP)), woff=64)]
+            dict(x=_rb(torch.relu(rnd(64, 6, NP))), woff=64)]      # a plain source next to a BN+ReLU one is post-ReLU
     gw, rw, gb, rb_ = _run_wgrad(N, P, M, dz, z, co(M), segs, (M, 128, 1), 128, 1)
     assert _l2(gw, rw) < 3e-4 and _l2(gb, rb_) < 2e-5, (_l2(gw, rw), _l2(gb, rb_))
     M, P = 8, 15

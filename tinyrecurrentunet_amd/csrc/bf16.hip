@@ -65,11 +65,22 @@ __device__ __forceinline__ BSegPos bseg_pos(const trunet_bseg& sg, int p) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Implicit GEMM (forward of Conv1d k = 1 / ConvTranspose1d / the strided first conv, and their data gradients).
-// A wave owns NRT <= 2 row tiles (64 output channels) of a tile (position p, 32 frames); for M > 64 two waves split the
-// rows.  Workgroups are renumbered so that each XCD (blockIdx % 8) walks a contiguous range of tiles: the taps of a
-// transposed conv re-read a source row at neighbouring positions, which then hit that XCD's L2.
-template <int NRT>
+// A wave owns NRT <= 2 row tiles (64 output channels) of a tile (position p, 64 frames = two MFMA column blocks sharing
+// every A fragment); for M > 64 two waves split the rows.  The kernel is bound by the bytes a CU keeps in flight (32 KB per
+// CU measured 2.0 TB/s), so a wave requests KG k-steps x 2 column blocks (x 2 tensors for a BatchNorm-backward pair) = 16
+// KiB before it touches the first: KG = 8 single-tensor, 4 two-tensor (TWO).  Workgroups are renumbered so that each XCD
+// (blockIdx % 8) walks a contiguous range of tiles: the taps of a transposed conv re-read a source row at neighbouring
+// positions, which then hit that XCD's L2.
+constexpr int BG_NCB = 2;                       // 32-frame column blocks per tile
+
+// PRO / EPI: compile-time prologue mode and epilogue flags of the hot launches (the instruction stream of the generic
+// form -- runtime mode / flag tests around every k-step and every 4-row output group -- kept the waves ISSUING 47 % of
+// their time at 2 waves per SIMD, i.e. the kernel was issue-bound at 2-3 TB/s); -1 = decided at run time (thin layers).
+// FULL: every segment has a multiple of 16 channels and M is a multiple of 32 (no channel guards).
+template <int NRT, int PRO, int EPI, bool FULL>
 __global__ __launch_bounds__(256, 2) void bgemm_kernel(const trunet_bgemm_args a) {
+    constexpr bool TWO = PRO < 0 || PRO == TRUNET_PRO_BNBWD;
+    constexpr int KG = TWO ? 4 : 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_[];
     u32x4* Al = (u32x4*)smem_;                                          // [nrt_all][nks_total][64] A fragments
     const int nrt_all = (a.M + 31) >> 5;
@@ -78,16 +89,18 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(const trunet_bgemm_args a
                                                                         // hoisted registers)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, c = lane & 31;
+    const int epi = EPI >= 0 ? EPI : a.epi;
+    auto has = [&](int f) { return EPI >= 0 ? (EPI & f) != 0 : (epi & f) != 0; };
 
     for (int i = tid; i < nrt_all * a.nks_total * 64; i += 256) Al[i] = ((const u32x4*)a.wfrag)[i];
     // coefficient image per (k-step, octet half, {c0,c1,c2}, channel): zero coefficients cover padded channels
     for (int i = tid; i < a.nks_total * 2 * 3 * 8; i += 256) Cf[i] = 0.f;
     for (int i = tid; i < 128; i += 256) {
         const bool ok = i < a.M;
-        Ep[i] = (ok && (a.epi & TRUNET_EPI_BIAS)) ? a.bias[i] : 0.f;
-        Ep[128 + i] = (ok && (a.epi & TRUNET_EPI_MASK)) ? a.e0[i] : 0.f;
-        Ep[256 + i] = (ok && (a.epi & TRUNET_EPI_MASK)) ? a.e1[i] : 0.f;
-        Ep[384 + i] = (ok && (a.epi & TRUNET_EPI_MASK) && a.e2) ? a.e2[i] : 0.f;
+        Ep[i] = (ok && has(TRUNET_EPI_BIAS)) ? a.bias[i] : 0.f;
+        Ep[128 + i] = (ok && has(TRUNET_EPI_MASK)) ? a.e0[i] : 0.f;
+        Ep[256 + i] = (ok && has(TRUNET_EPI_MASK)) ? a.e1[i] : 0.f;
+        Ep[384 + i] = (ok && has(TRUNET_EPI_MASK) && a.e2) ? a.e2[i] : 0.f;
     }
     __syncthreads();
     for (int s = 0; s < a.nseg; ++s) {
@@ -97,7 +110,8 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(const trunet_bgemm_args a
             const int oct = i >> 3, j = i & 7, ks = sg.kstep0 + (oct >> 1), hh = oct & 1;
             float* cf = Cf + ((ks * 2 + hh) * 3) * 8 + j;
             const bool real = i < sg.nchan;
-            if (sg.mode == TRUNET_PRO_NONE) { cf[0] = 1.f; cf[8] = 0.f; cf[16] = 0.f; }
+            // a TRUNET_PRO_NONE segment inside a BN+ReLU launch (a post-ReLU source: host contract) gets the identity
+            if (sg.mode == TRUNET_PRO_NONE) { cf[0] = real ? 1.f : 0.f; cf[8] = 0.f; cf[16] = 0.f; }
             else if (sg.mode == TRUNET_PRO_BNRELU) { cf[0] = real ? sg.c0[i] : 0.f; cf[8] = real ? sg.c1[i] : 0.f; cf[16] = 0.f; }
             else { cf[0] = real ? sg.c0[i] : 0.f; cf[8] = real ? sg.c1[i] : 0.f; cf[16] = real ? sg.c2[i] : 0.f; }
         }
@@ -106,14 +120,16 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(const trunet_bgemm_args a
 
     const int split = nrt_all > 2;                      // two waves share a tile (rows split)
     const int rt0 = split ? 2 * (wave & 1) : 0;
-    const int nrt = min(NRT, nrt_all - rt0);
+    const int nrt = FULL ? NRT : min(NRT, nrt_all - rt0);
     const int tslot = split ? (wave >> 1) : wave, tslots = split ? 2 : 4;
-    const int nfc = a.NP / 32;
+    const int nfc = a.NP / (32 * BG_NCB);
     const int total = a.P * nfc;
     const int vb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);      // XCD-contiguous numbering
+    const int moct = (a.M + 7) >> 3;
+    (void)moct;
 
-    // statistics: per tile the 16 values of a row tile are summed over the 32 frames of the half-wave by a butterfly that
-    // leaves value r(c) in lane c (1 register instead of 16): sacc[t][kind]
+    // statistics: per tile the 16 values of a row tile are summed over the 64 frames of the tile (two column blocks in
+    // registers, then a butterfly over the 32 lanes that leaves value r(c) in lane c: 1 live register instead of 16)
     float sacc[NRT][2];
 #pragma unroll
     for (int t = 0; t < NRT; ++t) { sacc[t][0] = 0.f; sacc[t][1] = 0.f; }
@@ -121,12 +137,14 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(const trunet_bgemm_args a
     for (int tile = vb * tslots + tslot; tile < total; tile += gridDim.x * tslots) {
         const int chunk = tile / a.P;
         const int p = a.p_begin + (tile - chunk * a.P);
-        const int n0 = chunk * 32;
-        f32x16 acc[NRT];
+        const int n0 = chunk * 32 * BG_NCB;
+        f32x16 acc[NRT][BG_NCB];
 #pragma unroll
         for (int t = 0; t < NRT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            for (int cb = 0; cb < BG_NCB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][cb][r] = 0.f;
 
         for (int s = 0; s < a.nseg; ++s) {
             const trunet_bseg& sg = a.seg[s];
@@ -135,41 +153,65 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(const trunet_bgemm_args a
             const int noct = (sg.nchan + 7) >> 3;
             const int nks = (noct + 1) >> 1;
             const size_t ostride = (size_t)sg.L * a.NP;                              // u32x4 elements between octets
-            const u32x4* b0 = (const u32x4*)sg.src0 + (size_t)sp.q * a.NP + n0 + c;
-            const u32x4* b1 = (const u32x4*)sg.src1 + (size_t)sp.q * a.NP + n0 + c;
-            const bool two = sg.mode == TRUNET_PRO_BNBWD;
-            for (int ks0 = 0; ks0 < nks; ks0 += 4) {
-                u32x4 r0[4], r1[4];
+            const u32x4* b0 = (const u32x4*)sg.src0 + (size_t)sp.q * a.NP + n0 + c + (size_t)h * ostride;
+            const u32x4* b1 = (const u32x4*)sg.src1 + (size_t)sp.q * a.NP + n0 + c + (size_t)h * ostride;
+            const int mode = PRO >= 0 ? PRO : sg.mode;
+            for (int ks0 = 0; ks0 < nks; ks0 += KG) {
+                u32x4 r0[KG][BG_NCB], r1[TWO ? KG : 1][BG_NCB];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int oct = 2 * (ks0 + j) + h;
-                    const bool ok = oct < noct;
+                for (int j = 0; j < KG; ++j) {
+                    const bool ok = FULL ? (ks0 + j < nks) : (2 * (ks0 + j) + h < noct);
                     const u32x4 z4 = {0u, 0u, 0u, 0u};
-                    r0[j] = ok ? b0[(size_t)oct * ostride] : z4;
-                    r1[j] = (ok && two) ? b1[(size_t)oct * ostride] : z4;
+                    const size_t o = (size_t)(2 * (ks0 + j)) * ostride;
+#pragma unroll
+                    for (int cb = 0; cb < BG_NCB; ++cb) {
+                        if (FULL) {
+                            if (ok) {       // wave-uniform
+                                r0[j][cb] = b0[o + 32 * cb];
+                                if constexpr (TWO) if (mode == TRUNET_PRO_BNBWD) r1[j][cb] = b1[o + 32 * cb];
+                            }
+                        } else {
+                            r0[j][cb] = ok ? b0[o + 32 * cb] : z4;
+                            if constexpr (TWO) r1[j][cb] = (ok && mode == TRUNET_PRO_BNBWD) ? b1[o + 32 * cb] : z4;
+                        }
+                    }
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < KG; ++j) {
                     asm volatile("" ::: "memory");          // keep the coefficient / fragment LDS reads of a k-step with it
                     if (ks0 + j < nks) {
                         const int ks = sg.kstep0 + ks0 + j;
                         const float* cf = Cf + ((ks * 2 + h) * 3) * 8;
-                        float v[8], w[8];
-                        bf_unpack8(r0[j], v);
-                        if (two) {
-                            bf_unpack8(r1[j], w);
+                        bf16x8 bfrag[BG_NCB];
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = fmaf(cf[e], v[e], fmaf(cf[8 + e], w[e], cf[16 + e]));
-                        } else if (sg.mode == TRUNET_PRO_BNRELU) {
+                        for (int cb = 0; cb < BG_NCB; ++cb) {
+                            if (mode == TRUNET_PRO_NONE) {
+                                bfrag[cb] = __builtin_bit_cast(bf16x8, r0[j][cb]);      // raw operand: no unpack / repack
+                            } else {
+                                float v[8];
+                                bf_unpack8(r0[j][cb], v);
+                                if constexpr (TWO) {
+                                    if (mode == TRUNET_PRO_BNBWD) {
+                                        float w[8];
+                                        bf_unpack8(r1[j][cb], w);
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(cf[e], v[e], cf[8 + e]), 0.f);
+                                        for (int e = 0; e < 8; ++e) v[e] = fmaf(cf[e], v[e], fmaf(cf[8 + e], w[e], cf[16 + e]));
+                                    }
+                                }
+                                if (mode == TRUNET_PRO_BNRELU) {
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(cf[e], v[e], cf[8 + e]), 0.f);
+                                }
+                                bfrag[cb] = __builtin_bit_cast(bf16x8, bf_pack8(v));
+                            }
                         }
-                        const bf16x8 bfrag = __builtin_bit_cast(bf16x8, bf_pack8(v));
 #pragma unroll
                         for (int t = 0; t < NRT; ++t) {
                             if (t < nrt) {
                                 const bf16x8 afrag = __builtin_bit_cast(bf16x8, Al[((size_t)(rt0 + t) * a.nks_total + ks) * 64 + lane]);
-                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[t], 0, 0, 0);
+#pragma unroll
+                                for (int cb = 0; cb < BG_NCB; ++cb)
+                                    acc[t][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[cb], acc[t][cb], 0, 0, 0);
                             }
                         }
                     }
@@ -178,7 +220,6 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(const trunet_bgemm_args a
         }
         // ---- epilogue: bias, accumulate, ReLU mask / ReLU, bf16 store (4 channels = 8 bytes per lane and octet), statistics
         // of the ROUNDED values
-        const bool fin = n0 + c < a.N;
 #pragma unroll
         for (int t = 0; t < NRT; ++t) {
             if (t >= nrt) continue;
@@ -188,60 +229,64 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(const trunet_bgemm_args a
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int m0 = (rt0 + t) * 32 + 8 * g + 4 * h;          // first of this lane's 4 rows
-                if (m0 >= a.M) continue;
-                const size_t eidx = (((size_t)((rt0 + t) * 4 + g) * a.out_L + p + a.out_pos_off) * a.NP + n0 + c) * 2 + h;
-                float val[4], zv[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) val[i] = acc[t][4 * g + i];
+                if (!FULL && m0 >= a.M) continue;
                 asm volatile("" ::: "memory");
-                if (a.epi & TRUNET_EPI_BIAS) {
-                    const f32x4 bv = *(const f32x4*)(Ep + m0);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) val[i] += bv[i];
-                }
-                if (a.epi & TRUNET_EPI_ACCUM) {
-                    const u32x2 o = ((const u32x2*)a.out)[eidx];
-                    val[0] += bf_lo(o[0]); val[1] += bf_hi(o[0]); val[2] += bf_lo(o[1]); val[3] += bf_hi(o[1]);
-                }
-                if (a.epi & TRUNET_EPI_MASK) {
-                    const u32x2 zz = ((const u32x2*)a.zmask)[eidx];
-                    zv[0] = bf_lo(zz[0]); zv[1] = bf_hi(zz[0]); zv[2] = bf_lo(zz[1]); zv[3] = bf_hi(zz[1]);
-                    const f32x4 e0v = *(const f32x4*)(Ep + 128 + m0), e1v = *(const f32x4*)(Ep + 256 + m0);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) val[i] = (fmaf(e0v[i], zv[i], e1v[i]) > 0.f) ? val[i] : 0.f;
-                }
-                if (a.epi & TRUNET_EPI_RELU) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) val[i] = fmaxf(val[i], 0.f);
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f}, e0v = bv, e1v = bv, muv = bv;
+                if (has(TRUNET_EPI_BIAS)) bv = *(const f32x4*)(Ep + m0);
+                if (has(TRUNET_EPI_MASK)) {
+                    e0v = *(const f32x4*)(Ep + 128 + m0);
+                    e1v = *(const f32x4*)(Ep + 256 + m0);
+                    if (has(TRUNET_EPI_STATS)) muv = *(const f32x4*)(Ep + 384 + m0);
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) if (m0 + i >= a.M) val[i] = 0.f;       // padded channels of the last octet
-                u32x2 o;
-                o[0] = bf_pack(val[0], val[1]);
-                o[1] = bf_pack(val[2], val[3]);
-                ((u32x2*)a.out)[eidx] = o;
-                if (a.epi & TRUNET_EPI_STATS) {
-                    const float rv[4] = {bf_lo(o[0]), bf_hi(o[0]), bf_lo(o[1]), bf_hi(o[1])};
-                    const f32x4 muv = *(const f32x4*)(Ep + 384 + m0);
+                for (int cb = 0; cb < BG_NCB; ++cb) {
+                    const int nn = n0 + 32 * cb + c;
+                    const size_t eidx = (((size_t)((rt0 + t) * 4 + g) * a.out_L + p + a.out_pos_off) * a.NP + nn) * 2 + h;
+                    float val[4], zv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float x = fin ? rv[i] : 0.f;
-                        st1[4 * g + i] = x;
-                        if (a.epi & TRUNET_EPI_MASK) {
-                            st2[4 * g + i] = x * (zv[i] - muv[i]);
-                        } else {
-                            st2[4 * g + i] = x * x;
+                    for (int i = 0; i < 4; ++i) val[i] = acc[t][cb][4 * g + i] + bv[i];
+                    if (has(TRUNET_EPI_ACCUM)) {
+                        const u32x2 o = ((const u32x2*)a.out)[eidx];
+                        val[0] += bf_lo(o[0]); val[1] += bf_hi(o[0]); val[2] += bf_lo(o[1]); val[3] += bf_hi(o[1]);
+                    }
+                    if (has(TRUNET_EPI_MASK)) {
+                        const u32x2 zz = ((const u32x2*)a.zmask)[eidx];
+                        zv[0] = bf_lo(zz[0]); zv[1] = bf_hi(zz[0]); zv[2] = bf_lo(zz[1]); zv[3] = bf_hi(zz[1]);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) val[i] = (fmaf(e0v[i], zv[i], e1v[i]) > 0.f) ? val[i] : 0.f;
+                    }
+                    if (has(TRUNET_EPI_RELU)) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) val[i] = fmaxf(val[i], 0.f);
+                    }
+                    if (!FULL) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) if (m0 + i >= a.M) val[i] = 0.f;   // padded channels of the last octet
+                    }
+                    u32x2 o;
+                    o[0] = bf_pack(val[0], val[1]);
+                    o[1] = bf_pack(val[2], val[3]);
+                    ((u32x2*)a.out)[eidx] = o;
+                    if (has(TRUNET_EPI_STATS)) {
+                        const float rv[4] = {bf_lo(o[0]), bf_hi(o[0]), bf_lo(o[1]), bf_hi(o[1])};
+                        const bool fin = nn < a.N;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float x = fin ? rv[i] : 0.f;
+                            st1[4 * g + i] += x;
+                            if (has(TRUNET_EPI_MASK)) st2[4 * g + i] = fmaf(x, zv[i] - muv[i], st2[4 * g + i]);
+                            else st2[4 * g + i] = fmaf(x, x, st2[4 * g + i]);
                         }
                     }
                 }
             }
-            if (a.epi & TRUNET_EPI_STATS) {
+            if (has(TRUNET_EPI_STATS)) {
                 sacc[t][0] += butterfly16(st1, c);
                 sacc[t][1] += butterfly16(st2, c);
             }
         }
     }
-    if (a.epi & TRUNET_EPI_STATS) {
+    if (has(TRUNET_EPI_STATS)) {
         float* pp = a.partials + ((size_t)(blockIdx.x * 4 + wave) * a.M_stat) * 2;
         const int r = butterfly16_index(c);
 #pragma unroll
@@ -283,8 +328,9 @@ __global__ void pack_weight_kernel(const float* __restrict__ W, u32x4* __restric
 // HBM exactly once per step -- applies the prologue (BatchNorm backward on dz, BN + ReLU on the sources, frames >= N
 // zeroed) and writes the result to LDS as [octet][frame][8 channels] (octet stride 64 frames * 16 B + 64 B, which makes
 // the transposed reads conflict-free).  ds_read_b64_tr_b16 then hands every lane 4 frames of one channel: two reads are
-// an MFMA fragment.  The loads of step t + 1 are in flight in registers while step t's MFMAs run; LDS is double-buffered,
-// one raw barrier per step.
+// an MFMA fragment.  The loads of steps t + 1 and t + 2 are in flight in registers while step t's MFMAs run (the kernel
+// is bound by how many bytes a CU keeps in flight: one step deep measured 1.5 TB/s); LDS is double-buffered, one raw
+// barrier per step.
 constexpr int BW_THREADS = 512;
 constexpr int BW_F = 64;                         // frames per step
 constexpr int BW_OS = BW_F * 16 + 64;            // LDS bytes between octets
@@ -305,14 +351,43 @@ __device__ __forceinline__ bf16x8 lds_frag(const unsigned char* img, int oct0, i
     return __builtin_bit_cast(bf16x8, f);
 }
 
+// TWO: dz = BatchNorm backward of (dy, z); SMODE: prologue of the sources (TRUNET_PRO_NONE / TRUNET_PRO_BNRELU; a plain
+// segment in a BN+ReLU launch must be a post-ReLU source and gets identity coefficients).  Coefficients live in LDS
+// ([octet][set][8] floats, broadcast reads): hoisted into scalar registers they spilled (318 SGPRs) and cost a v_readlane
+// per use.
+template <bool TWO, int SMODE>
 __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgrad_args a, int soct_total) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int moct = (a.M + 7) >> 3;
     const int nrt = (a.M + 31) >> 5;
-    const bool two = a.a_mode == TRUNET_PRO_BNBWD;
+    constexpr bool two = TWO;
     const int img_bytes = (moct + soct_total) * BW_OS;           // one buffer: dz octets, then the source octets
+    float* Cd = (float*)(smem_ + 2 * img_bytes);                 // [moct][3][8]  ca, cb, cc of dz (zero beyond M)
+    float* Cs = Cd + moct * 24;                                  // [source octet][2][8] scale, shift
+    for (int i = tid; i < moct * 8; i += BW_THREADS) {
+        const int oct = i >> 3, e = i & 7;
+        const bool ok = i < a.M;
+        Cd[oct * 24 + e] = two ? (ok ? a.ac0[i] : 0.f) : (ok ? 1.f : 0.f);
+        Cd[oct * 24 + 8 + e] = (two && ok) ? a.ac1[i] : 0.f;
+        Cd[oct * 24 + 16 + e] = (two && ok) ? a.ac2[i] : 0.f;
+    }
+    {
+        int base = 0;
+        for (int s = 0; s < a.nseg; ++s) {
+            const trunet_bseg& sg = a.seg[s];
+            const int no = (sg.nchan + 7) >> 3;
+            for (int i = tid; i < no * 8; i += BW_THREADS) {
+                const int oct = i >> 3, e = i & 7;
+                const bool ok = i < sg.nchan;
+                const bool bn = sg.mode == TRUNET_PRO_BNRELU;
+                Cs[(base + oct) * 16 + e] = ok ? (bn ? sg.c0[i] : 1.f) : 0.f;
+                Cs[(base + oct) * 16 + 8 + e] = (ok && bn) ? sg.c1[i] : 0.f;
+            }
+            base += no;
+        }
+    }
     // ---- this wave's operand octets
     int soct_seg[BW_MAXS], soct_idx[BW_MAXS], soct_g[BW_MAXS];   // segment, octet within the segment, global source octet
 #pragma unroll
@@ -363,10 +438,11 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
     const int s_begin = (int)(((long long)blockIdx.x * total) / gridDim.x);
     const int s_end = (int)(((long long)(blockIdx.x + 1) * total) / gridDim.x);
 
-    u32x4 rdy[BW_MAXD], rz[BW_MAXD], rs[BW_MAXS];
+    struct Stage { u32x4 dy[BW_MAXD], z[BW_MAXD], s[BW_MAXS]; };
+    Stage sa, sb;                                 // two steps of operand loads in flight
     const u32x4 z4 = {0u, 0u, 0u, 0u};
 
-    auto issue = [&](int st) {
+    auto issue = [&](int st, Stage& r) {
         const int chunk = st / a.P;
         const int p = a.p_begin + (st - chunk * a.P);
         const size_t n = (size_t)chunk * BW_F + lane;
@@ -375,8 +451,8 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
             const int oct = wave + 8 * j;
             if (oct < moct) {
                 const size_t idx = ((size_t)oct * a.a_L + p + a.a_pos_off) * a.NP + n;
-                rdy[j] = ((const u32x4*)a.a0)[idx];
-                if (two) rz[j] = ((const u32x4*)a.a1)[idx];
+                r.dy[j] = ((const u32x4*)a.a0)[idx];
+                if (two) r.z[j] = ((const u32x4*)a.a1)[idx];
             }
         }
 #pragma unroll
@@ -384,11 +460,11 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
             if (soct_seg[j] >= 0) {
                 const trunet_bseg& sg = a.seg[soct_seg[j]];
                 const BSegPos sp = bseg_pos(sg, p);
-                if (sp.valid) rs[j] = ((const u32x4*)sg.src0)[((size_t)soct_idx[j] * sg.L + sp.q) * a.NP + n];
+                if (sp.valid) r.s[j] = ((const u32x4*)sg.src0)[((size_t)soct_idx[j] * sg.L + sp.q) * a.NP + n];
             }
         }
     };
-    auto store = [&](int st, unsigned char* buf) {
+    auto store = [&](int st, unsigned char* buf, const Stage& r) {
         const int chunk = st / a.P;
         const int p = a.p_begin + (st - chunk * a.P);
         const bool fin = chunk * BW_F + lane < a.N;
@@ -397,18 +473,19 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
             const int oct = wave + 8 * j;
             if (oct < moct) {
                 float v[8], w[8];
-                bf_unpack8(rdy[j], v);
+                bf_unpack8(r.dy[j], v);
+                const float* cd = Cd + oct * 24;
                 if (two) {
-                    bf_unpack8(rz[j], w);
+                    bf_unpack8(r.z[j], w);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int m = min(oct * 8 + e, a.M - 1);
-                        v[e] = fmaf(a.ac0[m], v[e], fmaf(a.ac1[m], w[e], a.ac2[m]));
-                    }
+                    for (int e = 0; e < 8; ++e) v[e] = fmaf(cd[e], v[e], fmaf(cd[8 + e], w[e], cd[16 + e]));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= cd[e];          // 1, or 0 for the padded channels of the last octet
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    v[e] = (fin && oct * 8 + e < a.M) ? v[e] : 0.f;
+                    v[e] = fin ? v[e] : 0.f;
                     bsum[j][e] += v[e];
                 }
                 *(u32x4*)(buf + oct * BW_OS + lane * 16) = bf_pack8(v);
@@ -420,18 +497,19 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
                 const trunet_bseg& sg = a.seg[soct_seg[j]];
                 const BSegPos sp = bseg_pos(sg, p);
                 if (sp.valid) {
-                    float v[8];
-                    bf_unpack8(rs[j], v);
+                    if (SMODE == TRUNET_PRO_NONE && (sg.nchan & 7) == 0) {
+                        *(u32x4*)(buf + (moct + soct_g[j]) * BW_OS + lane * 16) = r.s[j];       // raw operand
+                    } else {
+                        float v[8];
+                        bf_unpack8(r.s[j], v);
+                        const float* cs = Cs + soct_g[j] * 16;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int ch = soct_idx[j] * 8 + e;
-                        if (sg.mode == TRUNET_PRO_BNRELU) {
-                            const int cc = min(ch, sg.nchan - 1);
-                            v[e] = fmaxf(fmaf(sg.c0[cc], v[e], sg.c1[cc]), 0.f);
+                        for (int e = 0; e < 8; ++e) {
+                            v[e] = fmaf(cs[e], v[e], cs[8 + e]);
+                            if (SMODE != TRUNET_PRO_NONE) v[e] = fmaxf(v[e], 0.f);
                         }
-                        if (ch >= sg.nchan) v[e] = 0.f;
+                        *(u32x4*)(buf + (moct + soct_g[j]) * BW_OS + lane * 16) = bf_pack8(v);
                     }
-                    *(u32x4*)(buf + (moct + soct_g[j]) * BW_OS + lane * 16) = bf_pack8(v);
                 }
             }
         }
@@ -457,14 +535,23 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
     for (int i = tid; i < 2 * img_bytes / 16; i += BW_THREADS) ((u32x4*)smem_)[i] = z4;
     __syncthreads();
 
-    if (s_begin < s_end) issue(s_begin);
-    for (int st = s_begin; st < s_end; ++st) {
-        unsigned char* buf = smem_ + ((st - s_begin) & 1) * img_bytes;
-        store(st, buf);
-        if (st + 1 < s_end) issue(st + 1);
+    unsigned char* buf0 = smem_;
+    unsigned char* buf1 = smem_ + img_bytes;
+    if (s_begin < s_end) issue(s_begin, sa);
+    if (s_begin + 1 < s_end) issue(s_begin + 1, sb);
+    for (int st = s_begin; st < s_end; st += 2) {
+        store(st, buf0, sa);
+        if (st + 2 < s_end) issue(st + 2, sa);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        mma(st, buf);
+        mma(st, buf0);
+        if (st + 1 < s_end) {
+            store(st + 1, buf1, sb);
+            if (st + 3 < s_end) issue(st + 3, sb);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            mma(st + 1, buf1);
+        }
     }
 
     // ---- partial image of dW (rows m = dz channel, columns c = source channel) and db
@@ -759,14 +846,39 @@ extern "C" int trunet_bf16_gemm(const trunet_bgemm_args* h, void* stream) {
     }
     const int nrt_all = (h->M + 31) / 32;
     const size_t lds = (size_t)nrt_all * h->nks_total * 64 * 16 + (size_t)h->nks_total * 2 * 3 * 8 * sizeof(float) + 4 * 128 * sizeof(float);
-    if (nrt_all == 1) {
-        if (hipFuncSetAttribute((const void*)bgemm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return TRUNET_ELAUNCH;
-        hipLaunchKernelGGL(bgemm_kernel<1>, dim3(BG_GRID), dim3(256), lds, ST, *h);
-    } else {
-        if (hipFuncSetAttribute((const void*)bgemm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return TRUNET_ELAUNCH;
-        hipLaunchKernelGGL(bgemm_kernel<2>, dim3(BG_GRID), dim3(256), lds, ST, *h);
+    // prologue class of the launch: BatchNorm-backward pairs, BN+ReLU (plain segments in it must be post-ReLU sources:
+    // they get identity coefficients), or plain
+    int pro = TRUNET_PRO_NONE;
+    bool full = (h->M % 32) == 0, mixed = false;
+    for (int s = 0; s < h->nseg; ++s) {
+        const int m = h->seg[s].mode;
+        if (m == TRUNET_PRO_BNBWD) pro = TRUNET_PRO_BNBWD;
+        else if (m == TRUNET_PRO_BNRELU && pro != TRUNET_PRO_BNBWD) pro = TRUNET_PRO_BNRELU;
+        full = full && (h->seg[s].nchan % 16) == 0;
     }
-    return trunet_launch_status();
+    for (int s = 0; s < h->nseg; ++s) mixed = mixed || (pro == TRUNET_PRO_BNBWD && h->seg[s].mode != TRUNET_PRO_BNBWD);
+    if (mixed) return TRUNET_ENOTSUP;
+#define BG_LAUNCH(NRT_, PRO_, EPI_, FULL_)                                                                                          \
+    do {                                                                                                                            \
+        if (hipFuncSetAttribute((const void*)bgemm_kernel<NRT_, PRO_, EPI_, FULL_>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                (int)lds) != hipSuccess)                                                                            \
+            return TRUNET_ELAUNCH;                                                                                                  \
+        hipLaunchKernelGGL((bgemm_kernel<NRT_, PRO_, EPI_, FULL_>), dim3(BG_GRID), dim3(256), lds, ST, *h);                         \
+        return trunet_launch_status();                                                                                              \
+    } while (0)
+    constexpr int B = TRUNET_EPI_BIAS, S = TRUNET_EPI_STATS, A = TRUNET_EPI_ACCUM, K = TRUNET_EPI_MASK;
+    if (full && nrt_all >= 2) {             // the hot launches of the training step
+        if (pro == TRUNET_PRO_BNRELU && h->epi == (B | S)) BG_LAUNCH(2, TRUNET_PRO_BNRELU, B | S, true);
+        if (pro == TRUNET_PRO_NONE && h->epi == (B | S)) BG_LAUNCH(2, TRUNET_PRO_NONE, B | S, true);
+        if (pro == TRUNET_PRO_BNBWD && h->epi == (K | S)) BG_LAUNCH(2, TRUNET_PRO_BNBWD, K | S, true);
+        if (pro == TRUNET_PRO_BNBWD && h->epi == (K | S | A)) BG_LAUNCH(2, TRUNET_PRO_BNBWD, K | S | A, true);
+        if (pro == TRUNET_PRO_BNBWD && h->epi == (K | A)) BG_LAUNCH(2, TRUNET_PRO_BNBWD, K | A, true);
+        if (pro == TRUNET_PRO_BNBWD && h->epi == 0) BG_LAUNCH(2, TRUNET_PRO_BNBWD, 0, true);
+    }
+    // everything else (thin layers, eval-mode forwards, the first conv): flags and modes tested at run time
+    if (nrt_all == 1) BG_LAUNCH(1, -1, -1, false);
+    BG_LAUNCH(2, -1, -1, false);
+#undef BG_LAUNCH
 }
 
 extern "C" int trunet_bf16_pack_weight(const float* W, void* wfrag, int M, int ldw_m, int ldw_c, int w_m_off, int nseg,
@@ -812,10 +924,20 @@ extern "C" int trunet_bf16_wgrad(const trunet_bwgrad_args* h, void* stream) {
     }
     if (soct > 8 * BW_MAXS || ((h->M + 31) / 32) * nct > 8 * BW_MAXT) return TRUNET_ENOTSUP;
     const int moct = ((h->M + 31) / 32) * 4;
-    const size_t lds = 2 * (size_t)(moct + soct) * BW_OS;
-    if (hipFuncSetAttribute((const void*)bwgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return TRUNET_ELAUNCH;
-    hipLaunchKernelGGL(bwgrad_kernel, dim3(trunet_conv_wgrad_nparts()), dim3(BW_THREADS), lds, ST, *h, soct);
+    const size_t lds = 2 * (size_t)(moct + soct) * BW_OS + (size_t)(moct * 24 + soct * 16) * sizeof(float);
+    bool bn = false;
+    for (int s = 0; s < h->nseg; ++s) bn = bn || h->seg[s].mode == TRUNET_PRO_BNRELU;
+    const bool two = h->a_mode == TRUNET_PRO_BNBWD;
+#define BW_LAUNCH(TWO_, SM_)                                                                                                       \
+    do {                                                                                                                           \
+        if (hipFuncSetAttribute((const void*)bwgrad_kernel<TWO_, SM_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=   \
+            hipSuccess)                                                                                                            \
+            return TRUNET_ELAUNCH;                                                                                                 \
+        hipLaunchKernelGGL((bwgrad_kernel<TWO_, SM_>), dim3(trunet_conv_wgrad_nparts()), dim3(BW_THREADS), lds, ST, *h, soct);     \
+    } while (0)
+    if (two) { if (bn) BW_LAUNCH(true, TRUNET_PRO_BNRELU); else BW_LAUNCH(true, TRUNET_PRO_NONE); }
+    else { if (bn) BW_LAUNCH(false, TRUNET_PRO_BNRELU); else BW_LAUNCH(false, TRUNET_PRO_NONE); }
+#undef BW_LAUNCH
     return trunet_launch_status();
 }
 

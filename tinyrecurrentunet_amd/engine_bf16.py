@@ -54,6 +54,23 @@ def _ksteps(nchan):
     return (_oct(nchan) + 1) // 2
 
 
+def _bgemm_name(M, segs, epi):
+    """The template instance trunet_bf16_gemm launches (mirror of its dispatch), as rocprofv3 prints it"""
+    pro = PRO_NONE
+    for s in segs:
+        if s.mode == PRO_BNBWD:
+            pro = PRO_BNBWD
+        elif s.mode == PRO_BNRELU and pro != PRO_BNBWD:
+            pro = PRO_BNRELU
+    full = M % 32 == 0 and all(s.nchan % 16 == 0 for s in segs)
+    B, S, A, K = EPI_BIAS, EPI_STATS, EPI_ACCUM, EPI_MASK
+    hot = {(PRO_BNRELU, B | S), (PRO_NONE, B | S), (PRO_BNBWD, K | S), (PRO_BNBWD, K | S | A), (PRO_BNBWD, K | A),
+           (PRO_BNBWD, 0)}
+    if full and M > 32 and (pro, epi) in hot:
+        return "bgemm_kernel<2, %d, %d, true>" % (pro, epi)
+    return "bgemm_kernel<%d, -1, -1, false>" % (1 if M <= 32 else 2)
+
+
 class TRUNetEngineBF16(TRUNetEngine):
     """TRUNetEngine with bf16 activation storage (see the module docstring)."""
 
@@ -104,7 +121,7 @@ class TRUNetEngineBF16(TRUNetEngine):
                 by += 2 * s.nchan * _seg_positions(s, p_begin, P) * (2 if s.mode == PRO_BNBWD else 1)
             by += 2 * M * P * (1 + (1 if epi & EPI_ACCUM else 0) + (1 if epi & EPI_MASK else 0))
             tag = "M%d K%s P%d" % (M, "+".join(str(s.nchan) for s in segs), P)
-            with _Timed("bgemm_kernel<%d>" % (1 if M <= 32 else 2), float(by) * N, tag):
+            with _Timed(_bgemm_name(M, segs, epi), float(by) * N, tag):
                 check(lib.trunet_bf16_gemm(a, st), "bf16_gemm")
             return nparts
         check(lib.trunet_bf16_gemm(a, st), "bf16_gemm")
@@ -133,7 +150,8 @@ class TRUNetEngineBF16(TRUNetEngine):
             a.b_stride, a.b_off = self._wg_total, b_off
         if E.PROFILE is not None:
             by = 2 * M * P * (2 if dz_bn is not None else 1) + sum(2 * s.nchan * _seg_positions(s, 0, P) for s in segs)
-            with _Timed("bwgrad_kernel", float(by) * N, "M%d K%s P%d" % (M, "+".join(str(s.nchan) for s in segs), P)):
+            with _Timed("bwgrad_kernel<%s, %d>" % ("true" if dz_bn is not None else "false",
+                                                    1 if any(s.mode == PRO_BNRELU for s in segs) else 0), float(by) * N, "M%d K%s P%d" % (M, "+".join(str(s.nchan) for s in segs), P)):
                 check(lib.trunet_bf16_wgrad(a, L.stream()), "bf16_wgrad")
         else:
             check(lib.trunet_bf16_wgrad(a, L.stream()), "bf16_wgrad")
