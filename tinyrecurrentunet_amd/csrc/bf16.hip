@@ -58,8 +58,13 @@ struct BSegPos { bool valid; int q; };
 __device__ __forceinline__ BSegPos bseg_pos(const trunet_bseg& sg, int p) {
     const int qn = p * sg.pos_mul + sg.pos_off;
     BSegPos r;
-    r.q = qn / sg.pos_div;
-    r.valid = (qn >= 0) && (qn - r.q * sg.pos_div == 0) && (r.q < sg.L);
+    // strides are 1 or 2 in this network: no integer division (~25 scalar instructions each) on the per-tile path
+    if (sg.pos_div == 1) { r.q = qn; r.valid = (qn >= 0) && (qn < sg.L); }
+    else if (sg.pos_div == 2) { r.q = qn >> 1; r.valid = (qn >= 0) && !(qn & 1) && (r.q < sg.L); }
+    else {
+        r.q = qn / sg.pos_div;
+        r.valid = (qn >= 0) && (qn - r.q * sg.pos_div == 0) && (r.q < sg.L);
+    }
     return r;
 }
 
@@ -440,12 +445,32 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
 
     struct Stage { u32x4 dy[BW_MAXD], z[BW_MAXD], s[BW_MAXS]; };
     Stage sa, sb;                                 // two steps of operand loads in flight
-    const u32x4 z4 = {0u, 0u, 0u, 0u};
-
-    auto issue = [&](int st, Stage& r) {
-        const int chunk = st / a.P;
-        const int p = a.p_begin + (st - chunk * a.P);
-        const size_t n = (size_t)chunk * BW_F + lane;
+    // what a step needs to know, computed ONCE per step in scalar registers (the three phases of a step used to redo
+    // the divisions: ~1000 scalar instructions per step, the bulk of the kernel's issue slots)
+    // a step is (chunk, p); segment positions come from per-piece / per-tile constants hoisted out of the loop (strides are
+    // 1 or 2: shifts, no integer division -- the three phases of a step used to redo ~16 divisions per step, ~1000 scalar
+    // instructions, the bulk of the kernel's issue slots)
+    struct Info { int chunk, p; };
+    struct PosC { int mul, off, sh, L; };
+    auto posc = [&](int sidx) {
+        PosC c;
+        const trunet_bseg& sg = a.seg[max(sidx, 0)];
+        c.mul = sg.pos_mul; c.off = sg.pos_off; c.sh = sg.pos_div >> 1; c.L = sg.L;       // pos_div in {1, 2} (host-checked)
+        return c;
+    };
+    auto pos = [&](const PosC& c, int p, bool& valid, int& q) {
+        const int qn = p * c.mul + c.off;
+        q = qn >> c.sh;
+        valid = (qn >= 0) && ((qn & c.sh) == 0) && (q < c.L);
+    };
+    PosC pc_s[BW_MAXS], pc_t[BW_MAXT];
+#pragma unroll
+    for (int j = 0; j < BW_MAXS; ++j) pc_s[j] = posc(soct_seg[j]);
+#pragma unroll
+    for (int i = 0; i < BW_MAXT; ++i) pc_t[i] = posc(t_seg[i]);
+    auto issue = [&](const Info& f, Stage& r) {
+        const int p = f.p;
+        const size_t n = (size_t)f.chunk * BW_F + lane;
 #pragma unroll
         for (int j = 0; j < BW_MAXD; ++j) {
             const int oct = wave + 8 * j;
@@ -459,15 +484,14 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
         for (int j = 0; j < BW_MAXS; ++j) {
             if (soct_seg[j] >= 0) {
                 const trunet_bseg& sg = a.seg[soct_seg[j]];
-                const BSegPos sp = bseg_pos(sg, p);
-                if (sp.valid) r.s[j] = ((const u32x4*)sg.src0)[((size_t)soct_idx[j] * sg.L + sp.q) * a.NP + n];
+                bool valid; int q;
+                pos(pc_s[j], f.p, valid, q);
+                if (valid) r.s[j] = ((const u32x4*)sg.src0)[((size_t)soct_idx[j] * sg.L + q) * a.NP + n];
             }
         }
     };
-    auto store = [&](int st, unsigned char* buf, const Stage& r) {
-        const int chunk = st / a.P;
-        const int p = a.p_begin + (st - chunk * a.P);
-        const bool fin = chunk * BW_F + lane < a.N;
+    auto store = [&](const Info& f, unsigned char* buf, const Stage& r) {
+        const bool fin = f.chunk * BW_F + lane < a.N;
 #pragma unroll
         for (int j = 0; j < BW_MAXD; ++j) {
             const int oct = wave + 8 * j;
@@ -495,8 +519,9 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
         for (int j = 0; j < BW_MAXS; ++j) {
             if (soct_seg[j] >= 0) {
                 const trunet_bseg& sg = a.seg[soct_seg[j]];
-                const BSegPos sp = bseg_pos(sg, p);
-                if (sp.valid) {
+                bool valid; int q;
+                pos(pc_s[j], f.p, valid, q);
+                if (valid) {
                     if (SMODE == TRUNET_PRO_NONE && (sg.nchan & 7) == 0) {
                         *(u32x4*)(buf + (moct + soct_g[j]) * BW_OS + lane * 16) = r.s[j];       // raw operand
                     } else {
@@ -514,13 +539,13 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
             }
         }
     };
-    auto mma = [&](int st, const unsigned char* buf) {
-        const int chunk = st / a.P;
-        const int p = a.p_begin + (st - chunk * a.P);
+    auto mma = [&](const Info& f, const unsigned char* buf) {
 #pragma unroll
         for (int i = 0; i < BW_MAXT; ++i) {
             if (t_rt[i] < 0) continue;
-            if (!bseg_pos(a.seg[t_seg[i]], p).valid) continue;
+            bool valid; int q;
+            pos(pc_t[i], f.p, valid, q);
+            if (!valid) continue;
 #pragma unroll
             for (int kk = 0; kk < BW_F / 16; ++kk) {
                 const bf16x8 af = lds_frag(buf, 4 * t_rt[i], 16 * kk, lane);
@@ -532,25 +557,35 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
 
     // rows of dz beyond moct that a 32-row tile still reads (M not a multiple of 32) and source octets beyond a segment's
     // last one inside its last 32-channel tile must read as zeros: clear both buffers once
-    for (int i = tid; i < 2 * img_bytes / 16; i += BW_THREADS) ((u32x4*)smem_)[i] = z4;
+    {
+        const u32x4 z4 = {0u, 0u, 0u, 0u};
+        for (int i = tid; i < 2 * img_bytes / 16; i += BW_THREADS) ((u32x4*)smem_)[i] = z4;
+    }
     __syncthreads();
 
     unsigned char* buf0 = smem_;
     unsigned char* buf1 = smem_ + img_bytes;
-    if (s_begin < s_end) issue(s_begin, sa);
-    if (s_begin + 1 < s_end) issue(s_begin + 1, sb);
+    Info nx;                                      // the next step to request: advanced incrementally (p fastest)
+    nx.chunk = s_begin / a.P;
+    nx.p = a.p_begin + (s_begin - nx.chunk * a.P);
+    auto advance = [&](Info& f) { if (++f.p == a.p_begin + a.P) { f.p = a.p_begin; ++f.chunk; } };
+    Info fa = nx, fb = nx;
+    if (s_begin < s_end) { issue(fa, sa); advance(nx); }
+    if (s_begin + 1 < s_end) { fb = nx; issue(fb, sb); advance(nx); }
     for (int st = s_begin; st < s_end; st += 2) {
-        store(st, buf0, sa);
-        if (st + 2 < s_end) issue(st + 2, sa);
+        store(fa, buf0, sa);
+        const Info fa_cur = fa;
+        if (st + 2 < s_end) { fa = nx; issue(fa, sa); advance(nx); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        mma(st, buf0);
+        mma(fa_cur, buf0);
         if (st + 1 < s_end) {
-            store(st + 1, buf1, sb);
-            if (st + 3 < s_end) issue(st + 3, sb);
+            store(fb, buf1, sb);
+            const Info fb_cur = fb;
+            if (st + 3 < s_end) { fb = nx; issue(fb, sb); advance(nx); }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            mma(st + 1, buf1);
+            mma(fb_cur, buf1);
         }
     }
 
@@ -918,6 +953,7 @@ extern "C" int trunet_bf16_wgrad(const trunet_bwgrad_args* h, void* stream) {
     for (int s = 0; s < h->nseg; ++s) {
         const trunet_bseg& sg = h->seg[s];
         if (!bseg_ok(sg) || sg.mode == TRUNET_PRO_BNBWD) return TRUNET_EINVAL;
+        if (sg.pos_div != 1 && sg.pos_div != 2) return TRUNET_ENOTSUP;          // the kernel's positions are shifts
         // a 32-channel tile reads 4 octets: round every segment up to whole tiles in the LDS image
         soct += ((sg.nchan + 31) / 32) * 4;
         nct += (sg.nchan + 31) / 32;
