@@ -562,3 +562,52 @@ def test_bf16_loss_within_one_percent_and_repeatable():
     g2 = [p.grad for n, p in b16.named_parameters() if p.grad is not None]
     assert l16b.item() == l16.item()
     assert all(torch.equal(a, b) for a, b in zip(g1, g2)), "bf16 step is not bitwise repeatable"
+
+
+def test_bf16_eval_forward_through_the_layer_kernels():
+    """eval() with the single-launch folded path switched off: the bf16 layer kernels with running statistics (bias-only
+    epilogue: the run-time-flag instances) against the fp32 layer kernels; odd frame counts incl. one frame"""
+    f32, b16 = _pair(4, seed=2)
+    g = torch.Generator(device=DEV)
+    g.manual_seed(21)
+    x = torch.randn(700, 4, 257, generator=g, device=DEV)
+    f32(x), b16(x)                                   # one training forward each: non-trivial running statistics
+    f32.eval(), b16.eval()
+    f32.fold_eval = b16.fold_eval = False
+    with torch.no_grad():
+        for N in (1, 63, 257, 700):
+            y32, y16 = f32(x[:N]), b16(x[:N])
+            assert y16.shape == (N, 8, 257) and torch.isfinite(y16).all()
+            assert _l2(y16, y32) < 5e-2, (N, _l2(y16, y32))
+
+
+def test_bf16_full_size_step_configs2_per_gpu_shape():
+    """BASELINE.json configs[2] per-GPU shape (64 x 4 s pairs = 32,064 frames, C_in = 4): loss and its terms within 1 % of
+    the fp32 HIP step (which test_configs_gpu pins against the fp32 oracle at this size), all gradients finite, and the
+    bf16 step bitwise repeatable"""
+    from tinyrecurrentunet_amd.stft_loss import MultiResolutionSTFTLoss
+    from tinyrecurrentunet_amd.util import loss_fn
+    f32, b16 = _pair(4, seed=4)
+    mr = MultiResolutionSTFTLoss(fft_sizes=[512, 1024, 2048], hop_sizes=[50, 120, 240], win_lengths=[240, 600, 1200],
+                                 window="hann_window", sc_lambda=0.5, mag_lambda=0.5, band="full").cuda()
+    g = torch.Generator(device=DEV)
+    g.manual_seed(31)
+    clean = 0.1 * torch.randn(64, 1, 64000, generator=g, device=DEV)
+    noisy = clean + 0.05 * torch.randn(64, 1, 64000, generator=g, device=DEV)
+    l32, d32 = loss_fn(f32, (clean, noisy), 1, 1.0, 1.0, mr)
+    del f32
+    runs = []
+    for _ in range(2):
+        b16.zero_grad(set_to_none=True)
+        for m in b16.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.reset_running_stats()
+        l16, d16 = loss_fn(b16, (clean, noisy), 1, 1.0, 1.0, mr)
+        l16.backward()
+        runs.append((l16.item(), [p.grad.clone() for n, p in b16.named_parameters() if p.grad is not None]))
+    assert abs(runs[0][0] - l32.item()) < 1e-2 * abs(l32.item()), (runs[0][0], l32.item())
+    for k in d32:
+        assert abs(d16[k].item() - d32[k].item()) < 2e-2 * abs(d32[k].item()) + 1e-5, (k, d16[k].item(), d32[k].item())
+    assert sum(t.numel() for t in runs[0][1]) == 298592
+    assert all(torch.isfinite(t).all() for t in runs[0][1])
+    assert runs[0][0] == runs[1][0] and all(torch.equal(a, b) for a, b in zip(runs[0][1], runs[1][1]))
