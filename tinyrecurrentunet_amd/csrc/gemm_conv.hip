@@ -589,6 +589,7 @@ extern "C" int trunet_conv_gemm(const trunet_gemm_args* h, void* stream) {
     for (int s = 0; s < h->nseg; ++s) {
         const trunet_seg& sg = h->seg[s];
         if (!sg.src0 || sg.nchan <= 0 || sg.pos_div <= 0 || sg.L <= 0) return TRUNET_EINVAL;
+        if (sg.pos_div > 2) return TRUNET_ENOTSUP;          // seg_pos works with shifts: strides 1 and 2
         if (sg.mode == TRUNET_PRO_BNBWD && (!sg.src1 || !sg.c0 || !sg.c1 || !sg.c2)) return TRUNET_EINVAL;
         if (sg.mode == TRUNET_PRO_BNRELU && (!sg.c0 || !sg.c1)) return TRUNET_EINVAL;
         any_two = any_two || sg.mode == TRUNET_PRO_BNBWD;
@@ -992,6 +993,7 @@ extern "C" int trunet_conv_wgrad(const trunet_wgrad_args* h, void* stream) {
     for (int s = 0; s < h->nseg; ++s) {
         const trunet_seg& sg = h->seg[s];
         if (!sg.src0 || sg.nchan <= 0 || sg.pos_div <= 0 || sg.L <= 0) return TRUNET_EINVAL;
+        if (sg.pos_div > 2) return TRUNET_ENOTSUP;          // seg_pos works with shifts: strides 1 and 2
         if (sg.mode == TRUNET_PRO_BNBWD) return TRUNET_ENOTSUP;
         if (sg.mode == TRUNET_PRO_BNRELU && (!sg.c0 || !sg.c1)) return TRUNET_EINVAL;
         const int srp = (sg.nchan + 31) & ~31;
