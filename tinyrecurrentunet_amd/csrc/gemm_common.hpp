@@ -45,15 +45,19 @@ __device__ __forceinline__ SegPos seg_pos(const trunet_seg& sg, int p) {
 struct ChunkIt {
     int tile, tile_end, p, n0, s, cc, ach, cbase;
     bool valid;
+    bool placed;        // p / n0 already hold the tile's position (kept incrementally: no division per tile)
 };
 
 template <int KC, int FT = NT>
 __device__ __forceinline__ void it_enter_tile(const trunet_gemm_args& a, ChunkIt& it) {
     it.valid = it.tile < it.tile_end;
     if (!it.valid) return;
-    const int nt = it.tile / a.P;
-    it.p = a.p_begin + (it.tile - nt * a.P);
-    it.n0 = nt * FT;
+    if (!it.placed) {           // first tile of the workgroup: one division; afterwards it_next steps p / n0
+        const int nt = it.tile / a.P;
+        it.p = a.p_begin + (it.tile - nt * a.P);
+        it.n0 = nt * FT;
+        it.placed = true;
+    }
     it.s = 0; it.cc = 0; it.ach = 0; it.cbase = 0;
     while (it.s < a.nseg - 1 && !seg_pos(a.seg[it.s], it.p).valid) {   // host contract: >= 1 valid segment
         it.ach += (a.seg[it.s].nchan + KC - 1) / KC;
@@ -78,6 +82,7 @@ __device__ __forceinline__ bool it_next(const trunet_gemm_args& a, ChunkIt& it) 
     }
     if (it.s < a.nseg) return false;
     ++it.tile;
+    if (++it.p == a.p_begin + a.P) { it.p = a.p_begin; it.n0 += FT; }      // tiles of a workgroup are consecutive, p fastest
     it_enter_tile<KC, FT>(a, it);
     return true;
 }

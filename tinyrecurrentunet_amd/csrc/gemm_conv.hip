@@ -71,6 +71,7 @@ __global__ __launch_bounds__(64 * NW, (EPL == 0 || NW == 8) ? 2 : 1) void conv_g
     const int ntn = a.NP / FT;
     const int total_tiles = a.P * ntn;
     ChunkIt cur;
+    cur.placed = false;
     cur.tile = (int)(((long long)blockIdx.x * total_tiles) / gridDim.x);
     cur.tile_end = (int)(((long long)(blockIdx.x + 1) * total_tiles) / gridDim.x);
     const bool has_work = cur.tile < cur.tile_end;
