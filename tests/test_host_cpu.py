@@ -341,6 +341,94 @@ def test_entry_points_reject_null_and_bad_shapes():
     assert lib.trunet_dwconv_fwd(None, None, None, None, None, None, None, 8, 3, 1, 4, 4, 256, 200, None) == EINVAL
 
 
+def test_bf16_entry_points_reject_null_and_bad_shapes():
+    """The trunet_bf16_* family validates on the host like the fp32 entry points (no launch, no GPU needed)."""
+    import ctypes as C
+    from tinyrecurrentunet_amd import _lib
+    lib = _lib.lib()
+    EINVAL, ENOTSUP = _lib.TRUNET_EINVAL, _lib.TRUNET_ENOTSUP
+    a = _lib.BGemmArgs()
+    a.NP, a.N, a.P, a.M, a.nseg, a.out_L, a.nks_total = 256, 200, 4, 64, 1, 4, 4
+    assert lib.trunet_bf16_gemm(a, None) == EINVAL                     # out / wfrag / segment source NULL
+    a.out, a.wfrag = 0x1000, 0x2000
+    sg = _lib.BSeg()
+    sg.src0, sg.nchan, sg.L, sg.pos_mul, sg.pos_div = 0x3000, 64, 4, 1, 1
+    a.seg[0] = sg
+    a.epi = _lib.EPI_MASK
+    assert lib.trunet_bf16_gemm(a, None) == EINVAL                     # mask without zmask / e0 / e1
+    a.epi = _lib.EPI_STATS
+    assert lib.trunet_bf16_gemm(a, None) == EINVAL                     # statistics without partials
+    a.epi = _lib.EPI_BIAS
+    assert lib.trunet_bf16_gemm(a, None) == EINVAL                     # bias flag without bias
+    a.epi = 0
+    a.seg[0].mode = _lib.PRO_BNBWD
+    assert lib.trunet_bf16_gemm(a, None) == EINVAL                     # BatchNorm-backward pair without src1 / coefficients
+    a.seg[0].mode = _lib.PRO_NONE
+    a.out_pos_off = 1
+    assert lib.trunet_bf16_gemm(a, None) == EINVAL                     # output rows run past out_L
+    a.out_pos_off = 0
+    a.nks_total = 2
+    assert lib.trunet_bf16_gemm(a, None) == EINVAL                     # packed weight image shorter than the segments
+    a.nks_total, a.NP = 4, 200
+    assert lib.trunet_bf16_gemm(a, None) == EINVAL                     # NP not a multiple of 64
+    a.NP, a.M = 256, 192
+    assert lib.trunet_bf16_gemm(a, None) == ENOTSUP                    # more than 128 rows
+    w = _lib.BWgradArgs()
+    w.NP, w.N, w.P, w.M, w.nseg, w.a_L, w.ldw_m, w.ldw_c, w.w_numel = 256, 200, 4, 64, 1, 4, 64, 1, 4096
+    w.seg[0] = sg
+    w.a0, w.w_partials = 0x1000, 0x2000
+    w.a_mode = _lib.PRO_BNBWD
+    assert lib.trunet_bf16_wgrad(w, None) == EINVAL                    # BatchNorm backward on dz without z / coefficients
+    w.a_mode, w.a_pos_off = _lib.PRO_NONE, 2
+    assert lib.trunet_bf16_wgrad(w, None) == EINVAL                    # dz rows run past a_L
+    w.a_pos_off = 0
+    w.seg[0].pos_div = 3
+    assert lib.trunet_bf16_wgrad(w, None) == ENOTSUP                   # positions are shifts: strides 1 and 2 only
+    w.seg[0].pos_div = 1
+    w.seg[0].nchan = 400
+    assert lib.trunet_bf16_wgrad(w, None) == ENOTSUP                   # more source octets than the LDS image holds
+    n3 = (C.c_int32 * 1)(64)
+    assert lib.trunet_bf16_pack_weight(None, 0x1000, 64, 64, 1, 0, 1, n3, n3, None) == EINVAL
+    assert lib.trunet_bf16_dwconv_fwd(0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 12, 3, 1, 8, 8, 256, 200,
+                                      None) == EINVAL                   # channels not a multiple of 8
+    assert lib.trunet_bf16_dwconv_fwd(0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 16, 3, 1, 8, 7, 256, 200,
+                                      None) == EINVAL                   # Lout inconsistent with (Lin, K, S)
+    assert lib.trunet_bf16_dwconv_fwd(0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000, None, 16, 3, 1, 8, 8, 256, 200,
+                                      None) == EINVAL                   # no partials buffer
+    assert lib.trunet_bf16_from_frames_last(None, 0x1000, 8, 4, 256, None) == EINVAL
+    assert lib.trunet_bf16_dw_nparts(512, 64) == 2 * 4 and lib.trunet_bf16_gemm_nparts() > 0
+    # fp32 GEMM family: strides other than 1 / 2 are refused (segment positions are computed with shifts)
+    g = _lib.GemmArgs()
+    g.NP, g.N, g.P, g.M, g.nseg, g.out_L, g.ldw_m, g.ldw_c = 256, 200, 4, 64, 1, 4, 64, 1
+    g.out, g.W = 0x1000, 0x2000
+    g.seg[0] = _lib.Seg()
+    g.seg[0].src0, g.seg[0].nchan, g.seg[0].L, g.seg[0].pos_mul, g.seg[0].pos_div = 0x3000, 64, 4, 1, 3
+    assert lib.trunet_conv_gemm(g, None) == ENOTSUP
+
+
+def test_bf16_kernel_name_mirror_and_precision_switch():
+    """engine_bf16._bgemm_name mirrors trunet_bf16_gemm's dispatch (bench.py matches it against rocprofv3 names);
+    TRUNet(precision=...) validates its argument without touching the GPU"""
+    from tinyrecurrentunet_amd import _lib
+    from tinyrecurrentunet_amd.engine_bf16 import _bgemm_name
+    from tinyrecurrentunet_amd.network import TRUNet
+
+    class S:
+        def __init__(self, nchan, mode):
+            self.nchan, self.mode = nchan, mode
+    B, St, A, K = _lib.EPI_BIAS, _lib.EPI_STATS, _lib.EPI_ACCUM, _lib.EPI_MASK
+    assert _bgemm_name(128, [S(128, _lib.PRO_BNRELU)], B | St) == "bgemm_kernel<2, 1, 3, true>"
+    assert _bgemm_name(64, [S(64, _lib.PRO_BNRELU), S(128, _lib.PRO_NONE)], B | St) == "bgemm_kernel<2, 1, 3, true>"
+    assert _bgemm_name(128, [S(64, _lib.PRO_BNBWD)], K | St | A) == "bgemm_kernel<2, 2, 14, true>"
+    assert _bgemm_name(64, [S(4, _lib.PRO_NONE)] * 5, B | _lib.EPI_RELU) == "bgemm_kernel<2, -1, -1, false>"
+    assert _bgemm_name(8, [S(64, _lib.PRO_BNRELU)], B | St) == "bgemm_kernel<1, -1, -1, false>"
+    net = TRUNet(input_size=4, precision="bf16")
+    assert net.precision == "bf16" and len(net.state_dict()) == 177
+    assert net.set_precision("fp32").precision == "fp32"
+    with pytest.raises(ValueError):
+        TRUNet(precision="fp16")
+
+
 def test_checkpoint_round_trip_with_reference_layout(tmp_path):
     """train.py:155-162 checkpoints ({'iter','model_state_dict','optimizer_state_dict','training_time_seconds'} as
     '<iter>.pkl') load both ways between the reference layout (oracle modules = the reference's own block classes in the
