@@ -138,14 +138,20 @@ __global__ __launch_bounds__(64 * NW, (EPL == 0 || NW == 8) ? 2 : 1) void conv_g
             const trunet_seg& sg = a.seg[it.s];
             const int q = seg_pos(sg, it.p).q;
             float* dst = R_lds + (size_t)slot * CHF;
+            // uniform base (position, first frame) + 32-bit per-lane element offset (channel row, frame): a tensor has
+            // fewer than 2^32 elements (host-checked), so no 64-bit multiplies per load
+            const size_t boff = (size_t)q * a.NP + it.n0;
+            const unsigned rstride = (unsigned)sg.L * (unsigned)a.NP;
+            const float* b0 = sg.src0 + boff;
+            const float* b1 = (TWO ? (sg.src1 ? sg.src1 : sg.src0) : sg.src0) + boff;
 #pragma unroll
             for (int i = 0; i < LPW; ++i) {
                 const int g = (LPW / NSRC) * wave8 + i / NSRC;
                 const int e = g * 256 + 4 * lane;
                 const int row = e / FT, col = e % FT;
                 const int cch = min(it.cc * KC + row, sg.nchan - 1);      // rows past the segment: finite filler (A = 0)
-                const float* src = (TWO && (i % NSRC)) ? (sg.src1 ? sg.src1 : sg.src0) : sg.src0;
-                const float* gp = src + ((size_t)cch * sg.L + q) * a.NP + it.n0 + col;
+                const unsigned off = (unsigned)cch * rstride + (unsigned)col;
+                const float* gp = ((TWO && (i % NSRC)) ? b1 : b0) + off;
                 __builtin_amdgcn_global_load_lds(gp, (lds_ptr_t)(dst + (i % NSRC) * (KC * FT) + g * 256), 16, 0, 0);
             }
         };
