@@ -394,6 +394,27 @@ typedef struct {
     trunet_bseg seg[TRUNET_MAX_SEG];
 } trunet_bwgrad_args;
 int trunet_bf16_wgrad(const trunet_bwgrad_args* h_args, void* stream);
+/* Fused backward of a Conv1d(k=1)+BatchNorm layer on octet tensors (autograd of network.py:28,50,64,83 + :96-98): the weight /
+ * bias gradient of trunet_bf16_wgrad AND, per source segment s, the data gradient
+ *     dsrc_s[c][p + pos_off_s][n] = sum_m W[m][woff_s + c] dz[m][p][n]
+ * in one pass over (dy, z, sources): flags[s] = TRUNET_DG_STORE | TRUNET_DG_MASK (zero where the source's BN+ReLU output is 0;
+ * a plain post-ReLU source: where it is 0) | TRUNET_DG_STATS (sum dsrc, sum dsrc (z_s - mean[s]) over valid frames into
+ * partials[s][trunet_bf16_pw_bwd_nparts()][nchan_s][2], zero-filled by the call) | TRUNET_DG_ACCUM (add to what out[s] holds).
+ * wfragT: W^T as A fragments, sources' 32-channel row tiles one after the other, each packed by
+ * trunet_bf16_pack_weight(W, ., nchan_s, 1, K, woff_s, 1, {M}, {0}); nrt_total = sum nchan_s / 32.
+ * Restrictions (else TRUNET_ENOTSUP: use trunet_bf16_wgrad + trunet_bf16_gemm): a_mode = TRUNET_PRO_BNBWD, pos_mul = pos_div = 1,
+ * nchan_s % 32 == 0, M % 16 == 0, at most 24 source octets, the LDS image within 160 KB. */
+typedef struct {
+    const void* wfragT;
+    void* out[TRUNET_MAX_SEG];
+    const float* mean[TRUNET_MAX_SEG];
+    float* partials[TRUNET_MAX_SEG];
+    int32_t flags[TRUNET_MAX_SEG];
+    int32_t nrt_total;
+} trunet_bdgrad_args;
+typedef struct { trunet_bwgrad_args w; trunet_bdgrad_args dg; } trunet_bpwbwd_args;
+int trunet_bf16_pw_bwd_nparts(void);
+int trunet_bf16_pw_bwd(const trunet_bpwbwd_args* h_args, void* stream);
 /* depthwise conv in the octet layout (network.py:33-38): BN+ReLU prologue on the input, raw bf16 output, fp32 statistics
  * partials[trunet_bf16_dw_nparts(NP, rows)][C][2] (rows = Lout forward, Lin backward); backward: dz = ca dy + cb z + cc, masked
  * data gradient of the input (+ its BatchNorm-backward sums), fp32 partial images w_partials[nparts][C][K],

@@ -84,6 +84,15 @@ class BWgradArgs(C.Structure):
                [("seg", BSeg * MAX_SEG)]
 
 
+class BDgradArgs(C.Structure):
+    _fields_ = [("wfragT", _fp), ("out", _fp * MAX_SEG), ("mean", _fp * MAX_SEG), ("partials", _fp * MAX_SEG),
+                ("flags", C.c_int32 * MAX_SEG), ("nrt_total", C.c_int32)]
+
+
+class BPwBwdArgs(C.Structure):
+    _fields_ = [("w", BWgradArgs), ("dg", BDgradArgs)]
+
+
 _lib = None
 
 
@@ -161,6 +170,8 @@ def _declare(L):
         "trunet_bf16_gemm": [C.POINTER(BGemmArgs), p],
         "trunet_bf16_pack_weight": [p, p, i, i, i, i, i, C.POINTER(C.c_int32), C.POINTER(C.c_int32), p],
         "trunet_bf16_wgrad": [C.POINTER(BWgradArgs), p],
+        "trunet_bf16_pw_bwd_nparts": [],
+        "trunet_bf16_pw_bwd": [C.POINTER(BPwBwdArgs), p],
         "trunet_bf16_dw_nparts": [i, i],
         "trunet_bf16_dwconv_fwd": [p, p, p, p, p, p, p, i, i, i, i, i, i, i, p],
         "trunet_bf16_dwconv_bwd": [p] * 14 + [i] * 7 + [p],

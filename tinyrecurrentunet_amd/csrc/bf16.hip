@@ -360,17 +360,41 @@ __device__ __forceinline__ bf16x8 lds_frag(const unsigned char* img, int oct0, i
 // segment in a BN+ReLU launch must be a post-ReLU source and gets identity coefficients).  Coefficients live in LDS
 // ([octet][set][8] floats, broadcast reads): hoisted into scalar registers they spilled (318 SGPRs) and cost a v_readlane
 // per use.
-template <bool TWO, int SMODE>
-__global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgrad_args a, int soct_total) {
+//
+// DG (trunet_bf16_pw_bwd): the data gradient of a pointwise layer in the same pass -- dsrc_s[c][p + off_s] = sum_m W[m][c] dz[m][p]
+// per source s, with the dz image as the MFMA B operand (an [octet][frame][8] row IS a B fragment: one ds_read_b128) and
+// W^T as A fragments in LDS; ReLU mask / statistics from a RAW copy of the source octets kept next to the activated one
+// (bitwise the arithmetic of the separate trunet_bf16_gemm launch), accumulate / store straight to HBM.  (dy, z) are read
+// once instead of twice and the BatchNorm-backward prologue runs once.
+template <bool TWO, int SMODE, bool DG>
+__global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgrad_args a, int soct_total,
+                                                               const trunet_bdgrad_args dg) {
+    constexpr int BW_MAXS = DG ? 3 : 5;             // source octets per wave (pointwise layers: <= 24 octets)
+    constexpr int BW_MAXT = DG ? 2 : 3;             // weight-gradient tiles per wave
+    constexpr int BW_MAXG = 2;                      // data-gradient tiles per wave: (32 source channels, 32 frames)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int moct = (a.M + 7) >> 3;
     const int nrt = (a.M + 31) >> 5;
     constexpr bool two = TWO;
-    const int img_bytes = (moct + soct_total) * BW_OS;           // one buffer: dz octets, then the source octets
+    // one buffer: dz octets, the (activated) source octets, and with DG the raw source octets
+    const int img_bytes = (moct + (DG ? 2 : 1) * soct_total) * BW_OS;
     float* Cd = (float*)(smem_ + 2 * img_bytes);                 // [moct][3][8]  ca, cb, cc of dz (zero beyond M)
     float* Cs = Cd + moct * 24;                                  // [source octet][2][8] scale, shift
+    float* Cm = Cs + soct_total * 16;                            // DG: [source octet][8] mean
+    u32x4* WT = (u32x4*)(Cm + (DG ? soct_total * 8 : 0));        // DG: W^T A fragments [source row tile][k-step][64]
+    const int nks_dz = (moct + 1) >> 1;
+    if constexpr (DG) {
+        for (int i = tid; i < dg.nrt_total * nks_dz * 64; i += BW_THREADS) WT[i] = ((const u32x4*)dg.wfragT)[i];
+        int base = 0;
+        for (int s = 0; s < a.nseg; ++s) {
+            const int no = (a.seg[s].nchan + 7) >> 3;
+            for (int i = tid; i < no * 8; i += BW_THREADS)
+                Cm[base * 8 + i] = (dg.mean[s] && i < a.seg[s].nchan) ? dg.mean[s][i] : 0.f;
+            base += no;
+        }
+    }
     for (int i = tid; i < moct * 8; i += BW_THREADS) {
         const int oct = i >> 3, e = i & 7;
         const bool ok = i < a.M;
@@ -427,6 +451,23 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
             }
         }
     }
+    // ---- DG: this wave's data-gradient tiles g = wave + 8 i -> (source row tile g / 2, frame half g % 2)
+    int d_seg[BW_MAXG], d_rtl[BW_MAXG], d_rtg[BW_MAXG], d_og[BW_MAXG];      // segment, row tile in it / overall, first octet
+    float sacc[BW_MAXG][2];
+#pragma unroll
+    for (int i = 0; i < BW_MAXG; ++i) {
+        d_seg[i] = -1; d_rtl[i] = 0; d_rtg[i] = 0; d_og[i] = 0; sacc[i][0] = 0.f; sacc[i][1] = 0.f;
+        if constexpr (DG) {
+            const int g = wave + 8 * i, rtg = g >> 1;
+            int rbase = 0, obase = 0;
+            for (int s = 0; s < a.nseg; ++s) {
+                const int nr = a.seg[s].nchan >> 5;
+                if (rtg >= rbase && rtg < rbase + nr) { d_seg[i] = s; d_rtl[i] = rtg - rbase; d_rtg[i] = rtg; d_og[i] = obase + 4 * (rtg - rbase); }
+                rbase += nr;
+                obase += a.seg[s].nchan >> 3;
+            }
+        }
+    }
     f32x16 acc[BW_MAXT];
 #pragma unroll
     for (int i = 0; i < BW_MAXT; ++i)
@@ -463,11 +504,13 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
         q = qn >> c.sh;
         valid = (qn >= 0) && ((qn & c.sh) == 0) && (q < c.L);
     };
-    PosC pc_s[BW_MAXS], pc_t[BW_MAXT];
+    PosC pc_s[BW_MAXS], pc_t[BW_MAXT], pc_d[BW_MAXG];
 #pragma unroll
     for (int j = 0; j < BW_MAXS; ++j) pc_s[j] = posc(soct_seg[j]);
 #pragma unroll
     for (int i = 0; i < BW_MAXT; ++i) pc_t[i] = posc(t_seg[i]);
+#pragma unroll
+    for (int i = 0; i < BW_MAXG; ++i) pc_d[i] = posc(d_seg[i]);
     auto issue = [&](const Info& f, Stage& r) {
         const int p = f.p;
         const size_t n = (size_t)f.chunk * BW_F + lane;
@@ -522,6 +565,7 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
                 bool valid; int q;
                 pos(pc_s[j], f.p, valid, q);
                 if (valid) {
+                    if constexpr (DG) *(u32x4*)(buf + (moct + soct_total + soct_g[j]) * BW_OS + lane * 16) = r.s[j];
                     if (SMODE == TRUNET_PRO_NONE && (sg.nchan & 7) == 0) {
                         *(u32x4*)(buf + (moct + soct_g[j]) * BW_OS + lane * 16) = r.s[j];       // raw operand
                     } else {
@@ -551,6 +595,68 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
                 const bf16x8 af = lds_frag(buf, 4 * t_rt[i], 16 * kk, lane);
                 const bf16x8 bfr = lds_frag(buf, moct + t_oct0[i], 16 * kk, lane);
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[i], 0, 0, 0);
+            }
+        }
+        if constexpr (DG) {
+            const int h = lane >> 5, c = lane & 31;
+#pragma unroll
+            for (int i = 0; i < BW_MAXG; ++i) {
+                if (d_seg[i] < 0) continue;
+                bool valid; int q;
+                pos(pc_d[i], f.p, valid, q);
+                if (!valid) continue;
+                const int cb = (wave + 8 * i) & 1;
+                f32x16 d;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d[r] = 0.f;
+                const unsigned char* bcol = buf + h * BW_OS + (32 * cb + c) * 16;
+                for (int ks = 0; ks < nks_dz; ++ks) {
+                    const bf16x8 af = __builtin_bit_cast(bf16x8, WT[(d_rtg[i] * nks_dz + ks) * 64 + lane]);
+                    const bf16x8 bfr = __builtin_bit_cast(bf16x8, *(const u32x4*)(bcol + 2 * ks * BW_OS));
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, d, 0, 0, 0);
+                }
+                const trunet_bseg& sg = a.seg[d_seg[i]];
+                const int flags = dg.flags[d_seg[i]];
+                u32x2* outp = (u32x2*)dg.out[d_seg[i]];
+                const int nn = f.chunk * BW_F + 32 * cb + c;
+                const bool fin = nn < a.N;
+                float st1[16], st2[16];
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int og = d_og[i] + g4;
+                    const size_t eidx = (((size_t)(d_rtl[i] * 4 + g4) * sg.L + q) * a.NP + nn) * 2 + h;
+                    float val[4], zv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) val[e] = d[4 * g4 + e];
+                    if (flags & 8) {        // accumulate onto the gradient already stored there (skip connection)
+                        const u32x2 o = outp[eidx];
+                        val[0] += bf_lo(o[0]); val[1] += bf_hi(o[0]); val[2] += bf_lo(o[1]); val[3] += bf_hi(o[1]);
+                    }
+                    f32x4 muv = {0.f, 0.f, 0.f, 0.f};
+                    if (flags & 2) {        // ReLU mask from the raw source
+                        const u32x2 zz = *(const u32x2*)(buf + (moct + soct_total + og) * BW_OS + (32 * cb + c) * 16 + 8 * h);
+                        zv[0] = bf_lo(zz[0]); zv[1] = bf_hi(zz[0]); zv[2] = bf_lo(zz[1]); zv[3] = bf_hi(zz[1]);
+                        const f32x4 e0v = *(const f32x4*)(Cs + og * 16 + 4 * h), e1v = *(const f32x4*)(Cs + og * 16 + 8 + 4 * h);
+                        muv = *(const f32x4*)(Cm + og * 8 + 4 * h);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) val[e] = (fmaf(e0v[e], zv[e], e1v[e]) > 0.f) ? val[e] : 0.f;
+                    }
+                    u32x2 o;
+                    o[0] = bf_pack(val[0], val[1]);
+                    o[1] = bf_pack(val[2], val[3]);
+                    outp[eidx] = o;
+                    const float rv[4] = {bf_lo(o[0]), bf_hi(o[0]), bf_lo(o[1]), bf_hi(o[1])};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = fin ? rv[e] : 0.f;
+                        st1[4 * g4 + e] = x;
+                        st2[4 * g4 + e] = x * (zv[e] - muv[e]);
+                    }
+                }
+                if (flags & 4) {
+                    sacc[i][0] += butterfly16(st1, c);
+                    sacc[i][1] += butterfly16(st2, c);
+                }
             }
         }
     };
@@ -602,6 +708,19 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
             const int m = t_rt[i] * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
             if (m < a.M && ci < sg.nchan)
                 img[(size_t)(m + a.w_m_off) * a.ldw_m + (size_t)ci * a.ldw_c + sg.woff] = acc[i][r];
+        }
+    }
+    if constexpr (DG) {
+        const int h = lane >> 5, c = lane & 31;
+        const int r = butterfly16_index(c);
+#pragma unroll
+        for (int i = 0; i < BW_MAXG; ++i) {
+            if (d_seg[i] < 0 || !(dg.flags[d_seg[i]] & 4)) continue;
+            const int cb = (wave + 8 * i) & 1;
+            const int nch = a.seg[d_seg[i]].nchan;
+            const int ch = d_rtl[i] * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+            float* pp = dg.partials[d_seg[i]] + ((size_t)(blockIdx.x * 2 + cb) * nch + ch) * 2;
+            if (!(c & 1)) { pp[0] = sacc[i][0]; pp[1] = sacc[i][1]; }
         }
     }
     if (a.b_partials) {
@@ -964,16 +1083,66 @@ extern "C" int trunet_bf16_wgrad(const trunet_bwgrad_args* h, void* stream) {
     bool bn = false;
     for (int s = 0; s < h->nseg; ++s) bn = bn || h->seg[s].mode == TRUNET_PRO_BNRELU;
     const bool two = h->a_mode == TRUNET_PRO_BNBWD;
+    trunet_bdgrad_args nodg = {};
 #define BW_LAUNCH(TWO_, SM_)                                                                                                       \
     do {                                                                                                                           \
-        if (hipFuncSetAttribute((const void*)bwgrad_kernel<TWO_, SM_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=   \
-            hipSuccess)                                                                                                            \
+        if (hipFuncSetAttribute((const void*)bwgrad_kernel<TWO_, SM_, false>, hipFuncAttributeMaxDynamicSharedMemorySize,         \
+                                (int)lds) != hipSuccess)                                                                           \
             return TRUNET_ELAUNCH;                                                                                                 \
-        hipLaunchKernelGGL((bwgrad_kernel<TWO_, SM_>), dim3(trunet_conv_wgrad_nparts()), dim3(BW_THREADS), lds, ST, *h, soct);     \
+        hipLaunchKernelGGL((bwgrad_kernel<TWO_, SM_, false>), dim3(trunet_conv_wgrad_nparts()), dim3(BW_THREADS), lds, ST, *h,     \
+                           soct, nodg);                                                                                            \
     } while (0)
     if (two) { if (bn) BW_LAUNCH(true, TRUNET_PRO_BNRELU); else BW_LAUNCH(true, TRUNET_PRO_NONE); }
     else { if (bn) BW_LAUNCH(false, TRUNET_PRO_BNRELU); else BW_LAUNCH(false, TRUNET_PRO_NONE); }
 #undef BW_LAUNCH
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_bf16_pw_bwd_nparts(void) { return 2 * trunet_conv_wgrad_nparts(); }
+
+extern "C" int trunet_bf16_pw_bwd(const trunet_bpwbwd_args* H, void* stream) {
+    if (!H) return TRUNET_EINVAL;
+    const trunet_bwgrad_args* h = &H->w;
+    const trunet_bdgrad_args* d = &H->dg;
+    if (!h->a0 || !h->w_partials || h->nseg < 1 || h->nseg > TRUNET_MAX_SEG || !d->wfragT) return TRUNET_EINVAL;
+    if (h->NP <= 0 || (h->NP % BW_F) != 0 || h->N <= 0 || h->N > h->NP || h->P <= 0 || h->M <= 0 || h->w_numel <= 0)
+        return TRUNET_EINVAL;
+    if (h->a_mode != TRUNET_PRO_BNBWD || !h->a1 || !h->ac0 || !h->ac1 || !h->ac2) return TRUNET_ENOTSUP;
+    if (h->a_L <= 0 || h->p_begin != 0 || h->a_pos_off != 0 || h->P > h->a_L) return TRUNET_EINVAL;
+    if (h->M > 128 || (h->M % 16) != 0) return TRUNET_ENOTSUP;
+    int soct = 0, nct = 0, nrt_total = 0;
+    bool bn = false;
+    for (int s = 0; s < h->nseg; ++s) {
+        const trunet_bseg& sg = h->seg[s];
+        if (!bseg_ok(sg) || sg.mode == TRUNET_PRO_BNBWD || !d->out[s]) return TRUNET_EINVAL;
+        if (sg.pos_mul != 1 || sg.pos_div != 1 || (sg.nchan % 32) != 0) return TRUNET_ENOTSUP;       // pointwise layers
+        if ((d->flags[s] & 4) && (!d->partials[s] || !d->mean[s] || !(d->flags[s] & 2))) return TRUNET_EINVAL;
+        bn = bn || sg.mode == TRUNET_PRO_BNRELU;
+        soct += sg.nchan / 8;
+        nct += sg.nchan / 32;
+        nrt_total += sg.nchan / 32;
+    }
+    if (nrt_total != d->nrt_total) return TRUNET_EINVAL;
+    if (soct > 8 * 3 || ((h->M + 31) / 32) * nct > 8 * 2 || 2 * nrt_total > 8 * 2) return TRUNET_ENOTSUP;
+    const int moct = ((h->M + 31) / 32) * 4, nks = (h->M / 8 + 1) / 2;
+    const size_t lds = 2 * (size_t)(moct + 2 * soct) * BW_OS + (size_t)(moct * 24 + soct * 24) * sizeof(float) +
+                       (size_t)nrt_total * nks * 64 * 16;
+    if (lds > 160 * 1024) return TRUNET_ENOTSUP;
+    for (int s = 0; s < h->nseg; ++s)
+        if (d->flags[s] & 4)
+            if (hipMemsetAsync(d->partials[s], 0, (size_t)trunet_bf16_pw_bwd_nparts() * h->seg[s].nchan * 2 * sizeof(float), ST) !=
+                hipSuccess)
+                return TRUNET_ELAUNCH;
+#define BWD_LAUNCH(SM_)                                                                                                            \
+    do {                                                                                                                           \
+        if (hipFuncSetAttribute((const void*)bwgrad_kernel<true, SM_, true>, hipFuncAttributeMaxDynamicSharedMemorySize,          \
+                                (int)lds) != hipSuccess)                                                                           \
+            return TRUNET_ELAUNCH;                                                                                                 \
+        hipLaunchKernelGGL((bwgrad_kernel<true, SM_, true>), dim3(trunet_conv_wgrad_nparts()), dim3(BW_THREADS), lds, ST, *h,      \
+                           soct, *d);                                                                                              \
+    } while (0)
+    if (bn) BWD_LAUNCH(TRUNET_PRO_BNRELU); else BWD_LAUNCH(TRUNET_PRO_NONE);
+#undef BWD_LAUNCH
     return trunet_launch_status();
 }
 

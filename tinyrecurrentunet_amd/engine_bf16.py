@@ -16,11 +16,18 @@ import torch
 
 from . import _lib as L
 from . import engine as E
-from ._lib import (EPI_ACCUM, EPI_BIAS, EPI_MASK, EPI_RELU, EPI_STATS, PRO_BNBWD, PRO_BNRELU, PRO_NONE, BGemmArgs, BSeg,
-                   BWgradArgs, check, ptr, ptr16)
+import os
+
+from ._lib import (DG_ACCUM, DG_MASK, DG_STATS, DG_STORE, EPI_ACCUM, EPI_BIAS, EPI_MASK, EPI_RELU, EPI_STATS, PRO_BNBWD,
+                   PRO_BNRELU, PRO_NONE, BGemmArgs, BPwBwdArgs, BSeg, BWgradArgs, check, ptr, ptr16)
 from .engine import BN_MOM, F_BINS, FRAME_PAD, Act, TRUNetEngine, _Timed, _seg_positions, ceil_to
 
 BF16 = torch.bfloat16
+
+# Backward of the pointwise convs: one fused launch (trunet_bf16_pw_bwd: weight gradient + every source's data gradient in one
+# pass over dy, z, sources) instead of trunet_bf16_wgrad + one trunet_bf16_gemm per source; TRUNET_BF16_FUSED_PWBWD=0 keeps the
+# separate launches (A/B measurements, and the reference the fused kernel is tested against bit for bit).
+FUSED_PWBWD16 = os.environ.get("TRUNET_BF16_FUSED_PWBWD", "1") != "0"
 
 
 def bseg(src0, nchan, Ln, pos_mul=1, pos_off=0, pos_div=1, woff=0, mode=PRO_NONE, src1=None, c0=None, c1=None, c2=None):
@@ -150,8 +157,8 @@ class TRUNetEngineBF16(TRUNetEngine):
             a.b_stride, a.b_off = self._wg_total, b_off
         if E.PROFILE is not None:
             by = 2 * M * P * (2 if dz_bn is not None else 1) + sum(2 * s.nchan * _seg_positions(s, 0, P) for s in segs)
-            with _Timed("bwgrad_kernel<%s, %d>" % ("true" if dz_bn is not None else "false",
-                                                    1 if any(s.mode == PRO_BNRELU for s in segs) else 0), float(by) * N, "M%d K%s P%d" % (M, "+".join(str(s.nchan) for s in segs), P)):
+            with _Timed("bwgrad_kernel<%s, %d, false>" % ("true" if dz_bn is not None else "false",
+                                                           1 if any(s.mode == PRO_BNRELU for s in segs) else 0), float(by) * N, "M%d K%s P%d" % (M, "+".join(str(s.nchan) for s in segs), P)):
                 check(lib.trunet_bf16_wgrad(a, L.stream()), "bf16_wgrad")
         else:
             check(lib.trunet_bf16_wgrad(a, L.stream()), "bf16_wgrad")
@@ -298,6 +305,9 @@ class TRUNetEngineBF16(TRUNetEngine):
         """Backward of a Conv1d(k=1)+BatchNorm layer: one weight-gradient launch, one data-gradient launch per source
         (ReLU mask / skip accumulation / BatchNorm-backward statistics in its epilogue)."""
         K = sum(s.nchan for s in segs)
+        if FUSED_PWBWD16 and dz_bn is not None and self._pw_bwd16_fused(w, N, NP, P, M, dz, dz1, dz_bn, W, bias, segs, outs,
+                                                                        grads, K):
+            return
         self._wgrad16(w, N=N, NP=NP, P=P, M=M, dz=dz, dz1=dz1, dz_L=P, dz_bn=dz_bn, W=W, ldw_m=K, ldw_c=1, segs=segs,
                       grads=grads, bias=bias)
         for sg, o in zip(segs, outs):
@@ -319,6 +329,71 @@ class TRUNetEngineBF16(TRUNetEngine):
                                   **kw)
             if src is not None and src.bn is not None:
                 self._bn_bwd(w, src.bn, nparts, grads)
+
+    def _pw_bwd16_fused(self, w, N, NP, P, M, dz, dz1, dz_bn, W, bias, segs, outs, grads, K):
+        """trunet_bf16_pw_bwd; False when the kernel does not take the shape (thin layers: the caller runs the separate
+        launches)"""
+        lib, st = L.lib(), L.stream()
+        if M % 16 or M > 128 or any(s.nchan % 32 or s.pos_mul != 1 or s.pos_div != 1 for s in segs):
+            return False
+        if sum(s.nchan for s in segs) > 192:
+            return False
+        nks = _ksteps(M)
+        nrt_total = sum(s.nchan // 32 for s in segs)
+        wfragT = w.flat("wfragT", nrt_total * nks * 64 * 8, dtype=BF16)
+        one = (C.c_int32 * 1)(M)
+        zero = (C.c_int32 * 1)(0)
+        rt0 = 0
+        for s in segs:       # W^T of this source: A(c, m) = W[m*K + woff + c]
+            rc = lib.trunet_bf16_pack_weight(ptr(W.data), wfragT.data_ptr() + rt0 * nks * 64 * 16, s.nchan, 1, K, s.woff, 1,
+                                             one, zero, st)
+            if rc != nks:
+                raise L.TrunetHipError("trunet_bf16_pack_weight (W^T): code %d" % rc)
+            rt0 += s.nchan // 32
+        a = BPwBwdArgs()
+        aw = a.w
+        aw.NP, aw.N, aw.P, aw.p_begin = NP, N, P, 0
+        aw.M, aw.a_L, aw.a_pos_off, aw.a_mode = M, P, 0, PRO_BNBWD
+        aw.ldw_m, aw.ldw_c, aw.w_m_off, aw.nseg = K, 1, 0, len(segs)
+        aw.a0, aw.a1 = ptr16(dz), ptr16(dz1)
+        aw.ac0, aw.ac1, aw.ac2 = ptr(dz_bn.ca), ptr(dz_bn.cb), ptr(dz_bn.cc)
+        aw.w_numel = self._wg_total
+        aw.w_partials, aw.b_partials = self._wg_slot(W), self._wg_slot(bias)
+        aw.b_stride, aw.b_off = self._wg_total, 0
+        a.dg.wfragT, a.dg.nrt_total = ptr16(wfragT), nrt_total
+        nparts = lib.trunet_bf16_pw_bwd_nparts()
+        stat_parts = []
+        for i, (sg, o) in enumerate(zip(segs, outs)):
+            aw.seg[i] = sg
+            a.dg.out[i] = ptr16(o["out"])
+            fl = DG_STORE
+            src = o.get("src")
+            if src is not None:
+                fl |= DG_MASK
+                if src.bn is not None:
+                    fl |= DG_STATS
+                    part = w.flat("pwb16_partials%d" % i, nparts * sg.nchan * 2)
+                    a.dg.mean[i], a.dg.partials[i] = ptr(src.bn.mean), ptr(part)
+                    stat_parts.append((src.bn, "pwb16_partials%d" % i))
+            if o.get("accum"):
+                fl |= DG_ACCUM
+            a.dg.flags[i] = fl
+        if E.PROFILE is not None:
+            by = 2 * M * P * 2
+            for sg, o in zip(segs, outs):
+                npos = _seg_positions(sg, 0, P)
+                by += 2 * sg.nchan * npos * (2 + (1 if o.get("accum") else 0))       # source read, gradient written (+ read)
+            with _Timed("bwgrad_kernel<true, %d, true>" % (1 if any(s.mode == PRO_BNRELU for s in segs) else 0),
+                        float(by) * N, "M%d K%s P%d" % (M, "+".join(str(s.nchan) for s in segs), P)):
+                rc = lib.trunet_bf16_pw_bwd(a, st)
+        else:
+            rc = lib.trunet_bf16_pw_bwd(a, st)
+        if rc == L.TRUNET_ENOTSUP:
+            return False
+        check(rc, "bf16_pw_bwd")
+        for bn, pname in stat_parts:
+            self._bn_bwd(w, bn, nparts, grads, part_name=pname)
+        return True
 
     def _bwd_tr16(self, w, N, NP, ct, pw, a_pw, Lo, up, x1, x1_mask, skip, left, dy_x1, g_skip, dy_pw_name, grads):
         """FirstTrCNN / TrCNN / LastTrCNN (network.py:60-120): transposed conv, then the pointwise conv over [x1 | skip]"""
