@@ -107,7 +107,7 @@ def cpu_baseline(B=4, L=64000, steps=10, budget_s=45.0):
                 B, B * T, len(tt), torch.__version__)}
 
 
-def streaming(args, dev):
+def streaming(args, dev, emit=True):
     """rt.py:20-27,76-84 protocol on the GPU: eval-mode forward of a fresh randn (streams, 4, 257) batch under
     no_grad, one STFT frame (8 ms of 16 kHz audio) per stream per step; frames are independent in the reference
     forward (no TGRU, R4), so `streams` concurrent streams are one batch of `streams` frames."""
@@ -200,7 +200,42 @@ def streaming(args, dev):
            "roofline": roof, "cpu_baseline": cpu}
     if cpu:
         out["gpu_over_cpu"] = round(out["value"] / cpu["value"], 1)
+    if not emit:
+        return out
     print(json.dumps(out), flush=True)
+
+
+def other_configs(args, dev, step_factory):
+    """Short measurements of BASELINE.json configs[2] (bf16 train step, this GPU's share) and configs[3] (1024-stream
+    forward), attached to the headline line as context (`other_configs`); each is its own bench mode with its own
+    roofline (`--dtype bf16`, `--streaming`)."""
+    import copy
+    out = {}
+    try:
+        step16, frames = step_factory("bf16")
+        for _ in range(3):
+            step16()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(10):
+            step16()
+        torch.cuda.synchronize()
+        dt = (time.time() - t0) / 10
+        out["bf16_train_step"] = {"value": round(frames / dt, 1), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 3),
+                                  "steps": 10, "dtype": "bf16", "how": "python bench.py --dtype bf16"}
+        del step16
+        torch.cuda.empty_cache()
+    except Exception as e:      # context only: never take the headline line down
+        out["bf16_train_step"] = {"error": repr(e)}
+    try:
+        a2 = copy.copy(args)
+        a2.steps, a2.warmup, a2.no_cpu_baseline, a2.tgru = 200, 3, True, False
+        r = streaming(a2, dev, emit=False)
+        out["streaming_1024"] = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
+                                 "steps": 200, "dtype": "f32", "how": "python bench.py --streaming"}
+    except Exception as e:
+        out["streaming_1024"] = {"error": repr(e)}
+    return out
 
 
 def main():
@@ -211,6 +246,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
     ap.add_argument("--seconds", type=float, default=4.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the short bf16 / streaming context measurements")
     ap.add_argument("--no-stft-loss", action="store_true", help="ablation (BASELINE.json configs[4])")
     ap.add_argument("--no-pcen", action="store_true", help="ablation (BASELINE.json configs[4])")
     ap.add_argument("--force-dist", action="store_true",
@@ -373,6 +409,21 @@ def main():
                 "kernel_ms_per_step": {k: round(v[0], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])},
                 "step_flop_frac_of_peak": round(value / world * FLOPS_PER_FRAME_STEP / 1e12 / PEAK_F32_TFLOPS, 4),
                 "step_hbm_GBps_layer_model": round(value / world * HBM_BYTES_PER_FRAME_STEP / 1e9, 1)}
+    extras = None
+    if rank == 0 and world == 1 and not args.no_extras and args.dtype == "f32" and not (
+            args.tgru or args.no_stft_loss or args.no_pcen):
+        def step_factory(precision):
+            torch.manual_seed(0)
+            net2 = hn.TRUNet(input_size=cin, precision=precision).to(dev).train()
+            opt2 = optim.FusedAdamW(net2.parameters(), lr=4e-4)
+
+            def step2():
+                opt2.zero_grad()
+                l2, _ = util.loss_fn(net2, (clean, noisy), ell_p=1, ell_p_lambda=1, stft_lambda=1, mrstftloss=mr)
+                l2.backward()
+                return opt2.step()
+            return step2, frames
+        extras = other_configs(args, dev, step_factory)
     if rank == 0:
         cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()
         out = {"metric": "16 kHz frames/sec (train step)", "value": round(value, 1), "unit": "frames/s",
@@ -393,6 +444,8 @@ def main():
                "roofline": roof, "cpu_baseline": cpu}
         if cpu:
             out["gpu_over_cpu"] = round(value / cpu["value"], 1)
+        if extras:
+            out["other_configs"] = extras
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
