@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, precision):
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
     from oracle import network_ref as nr, weights as W
@@ -23,7 +23,7 @@ def _worker(rank, world, port, q):
     torch.cuda.set_device(0)
     # rank-dependent initial weights: the start-up broadcast must make them rank 0's
     sd = W.fill_state_dict(nr.TRUNet(input_size=4), seed=10 + rank).state_dict()
-    net = hn.TRUNet(input_size=4)
+    net = hn.TRUNet(input_size=4, precision=precision)
     net.load_state_dict(sd)
     net.cuda().train()
     td.apply_gradient_allreduce(net)
@@ -38,7 +38,7 @@ def _worker(rank, world, port, q):
     # expected: mean over ranks of the local gradients from rank 0's weights (BatchNorm statistics stay per rank)
     exp = 0
     for r in range(world):
-        ref = hn.TRUNet(input_size=4)
+        ref = hn.TRUNet(input_size=4, precision=precision)
         ref.load_state_dict(W.fill_state_dict(nr.TRUNet(input_size=4), seed=10).state_dict())
         ref.cuda().train()
         yy = ref(xs[r])
@@ -49,7 +49,10 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_dp_step_matches_mean_of_local_gradients():
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_two_rank_dp_step_matches_mean_of_local_gradients(precision):
+    """fp32, and the bf16 engine of BASELINE.json configs[2] (its parameter gradients are the same flat fp32 tensor, so the
+    all-reduce path is shared; the step is deterministic, so the mean of the local gradients is reproduced exactly)"""
     import socket
     world = 2
     with socket.socket() as sk:            # a port that is free right now (a fixed one can be in TIME_WAIT)
@@ -57,7 +60,7 @@ def test_two_rank_dp_step_matches_mean_of_local_gradients():
         port = sk.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q, precision)) for r in range(world)]
     [p.start() for p in ps]
     try:
         res = [q.get(timeout=300) for _ in range(world)]
@@ -71,7 +74,8 @@ def test_two_rank_dp_step_matches_mean_of_local_gradients():
         assert err < 1e-5, (rank, err)
 
 
-def test_bench_two_ranks_complete_without_deadlock():
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_bench_two_ranks_complete_without_deadlock(dtype):
     """bench.py under torch.distributed.run with 2 ranks (both on cuda:0, gloo instead of RCCL: this box has one GPU).
     Guards the control flow of the multi-GPU benchmark: every rank must take part in every step that contains the
     gradient all-reduce, including the instrumented one after the timed region."""
@@ -84,10 +88,10 @@ def test_bench_two_ranks_complete_without_deadlock():
     env = dict(os.environ, TRUNET_BENCH_ONE_DEVICE="1", TRUNET_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "1", "--batch", "4", "--seconds", "1"]
+           "--warmup", "1", "--batch", "4", "--seconds", "1", "--dtype", dtype]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 8 and res["value"] > 0
-    assert res["roofline"] is not None and res["cpu_baseline"] is None
+    assert res["roofline"] is not None and res["cpu_baseline"] is None and res["dtype"] == dtype
