@@ -20,25 +20,53 @@ __device__ __forceinline__ cpx cconj(cpx a) { return make_float2(a.x, -a.y); }
 // tw[t] = exp(-2*pi*i*t/n), t < n/2.  inverse => conjugated twiddles (unnormalised).
 // Returns the buffer (a or b) that holds the natural-order result.  Ends with a barrier.
 __device__ cpx* fft_lds(cpx* a, cpx* b, int n, int logn, const cpx* __restrict__ tw, bool inverse) {
-    const int half = n >> 1;
+    // Stockham autosort, radix 4 (one radix-2 stage first when log2 n is odd): 5 / 5 / 6 barriers for n = 512 / 1024 / 2048
+    // instead of 9 / 10 / 11, and half the LDS traffic
+    const int half = n >> 1, quarter = n >> 2;
     cpx* x = a;
     cpx* y = b;
     int ns = 1;
-    for (int s = 0; s < logn; ++s) {
+    int s = 0;
+    if (logn & 1) {
         __syncthreads();
-        const int tstep = half >> s;  // n / (2*ns)
         for (int j = threadIdx.x; j < half; j += blockDim.x) {
-            const int k = j & (ns - 1);
-            cpx w = tw[k * tstep];
-            if (inverse) w.y = -w.y;
-            const cpx u = x[j];
-            const cpx v = cmul(w, x[j + half]);
-            const int j0 = ((j - k) << 1) + k;
-            y[j0] = make_float2(u.x + v.x, u.y + v.y);
-            y[j0 + ns] = make_float2(u.x - v.x, u.y - v.y);
+            const cpx u = x[j], v = x[j + half];
+            y[2 * j] = make_float2(u.x + v.x, u.y + v.y);
+            y[2 * j + 1] = make_float2(u.x - v.x, u.y - v.y);
         }
         cpx* t = x; x = y; y = t;
-        ns <<= 1;
+        ns = 2;
+        s = 1;
+    }
+    for (; s < logn; s += 2) {
+        __syncthreads();
+        const int tstep = quarter / ns;          // twiddle index step: exp(-2 pi i k / (4 ns)) = tw[k * n / (4 ns)]
+        for (int j = threadIdx.x; j < quarter; j += blockDim.x) {
+            const int k = j & (ns - 1);
+            const int t1 = k * tstep;
+            cpx w1 = tw[t1], w2 = tw[2 * t1];
+            const int t3 = 3 * t1;
+            cpx w3 = tw[t3 >= half ? t3 - half : t3];
+            if (t3 >= half) { w3.x = -w3.x; w3.y = -w3.y; }
+            if (inverse) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
+            const cpx u0 = x[j];
+            const cpx u1 = cmul(w1, x[j + quarter]);
+            const cpx u2 = cmul(w2, x[j + 2 * quarter]);
+            const cpx u3 = cmul(w3, x[j + 3 * quarter]);
+            const cpx v0 = make_float2(u0.x + u2.x, u0.y + u2.y);
+            const cpx v1 = make_float2(u0.x - u2.x, u0.y - u2.y);
+            const cpx v2 = make_float2(u1.x + u3.x, u1.y + u3.y);
+            const cpx d = make_float2(u1.x - u3.x, u1.y - u3.y);
+            // forward: (-i) d = (d.y, -d.x); inverse: (+i) d = (-d.y, d.x)
+            const cpx v3 = inverse ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x);
+            const int j0 = ((j - k) << 2) + k;
+            y[j0] = make_float2(v0.x + v2.x, v0.y + v2.y);
+            y[j0 + ns] = make_float2(v1.x + v3.x, v1.y + v3.y);
+            y[j0 + 2 * ns] = make_float2(v0.x - v2.x, v0.y - v2.y);
+            y[j0 + 3 * ns] = make_float2(v1.x - v3.x, v1.y - v3.y);
+        }
+        cpx* t = x; x = y; y = t;
+        ns <<= 2;
     }
     __syncthreads();
     return x;
@@ -308,7 +336,7 @@ __global__ __launch_bounds__(256) void stft_loss_fwd_kernel(const float* __restr
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
     cpx* sa = (cpx*)smraw;
     cpx* sb = sa + n;
-    __shared__ double red[256];
+    __shared__ double red[12];
     const int f = blockIdx.x, b = blockIdx.y;
     const float* xb = x + (size_t)b * L;
     const float* yb = y + (size_t)b * L;
@@ -329,11 +357,16 @@ __global__ __launch_bounds__(256) void stft_loss_fwd_kernel(const float* __restr
         s2 = fmaf(ym, ym, s2);
         s3 += fabsf(logf(ym) - logf(xm));
     }
-    double r;
-    float* pp = partials + ((size_t)b * nframes + f) * 3;
-    r = block_sum_f64((double)s1, red); if (threadIdx.x == 0) pp[0] = (float)r;
-    r = block_sum_f64((double)s2, red); if (threadIdx.x == 0) pp[1] = (float)r;
-    r = block_sum_f64((double)s3, red); if (threadIdx.x == 0) pp[2] = (float)r;
+    // three sums of <= 1025 terms: wave shuffles, then the four waves through LDS in fp64 (one barrier instead of the ~30
+    // of three tree reductions: they cost more than the FFT itself)
+    s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[wave * 3 + 0] = (double)s1; red[wave * 3 + 1] = (double)s2; red[wave * 3 + 2] = (double)s3; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float* pp = partials + ((size_t)b * nframes + f) * 3;
+        pp[threadIdx.x] = (float)((red[threadIdx.x] + red[3 + threadIdx.x]) + (red[6 + threadIdx.x] + red[9 + threadIdx.x]));
+    }
 }
 
 // stft() of stft_loss.py:9-30 for two signals at once: magnitudes sqrt(clamp(re^2 + im^2, 1e-7)) as (B, frames, bins)
