@@ -404,6 +404,9 @@ def main():
           roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": traffic,
                 "traffic_GBps": (round(traffic / (tot_ms / n * 1e-3) / 1e9, 1) if traffic else None),
+                # the kernel sits at the machine's ridge point (157.3 TF / 8 TB/s = 19.7 flop/B): both fractions matter
+                "traffic_frac_of_hbm_peak": (round(traffic / (tot_ms / n * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4) if traffic else None),
+                "flop_per_hbm_byte": (round(flops / n / traffic, 1) if traffic else None),
                 "traffic_source": traffic_src, "traffic_measured_on_other_kernel_source": traffic_stale,
                 "launches_per_step": n, "avg_launch_ms": round(tot_ms / n, 4),
                 "kernel_ms_per_step": {k: round(v[0], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])},
