@@ -420,8 +420,9 @@ def test_bf16_kernel_name_mirror_and_precision_switch():
     assert _bgemm_name(128, [S(128, _lib.PRO_BNRELU)], B | St) == "bgemm_kernel<2, 1, 3, true>"
     assert _bgemm_name(64, [S(64, _lib.PRO_BNRELU), S(128, _lib.PRO_NONE)], B | St) == "bgemm_kernel<2, 1, 3, true>"
     assert _bgemm_name(128, [S(64, _lib.PRO_BNBWD)], K | St | A) == "bgemm_kernel<2, 2, 14, true>"
-    assert _bgemm_name(64, [S(4, _lib.PRO_NONE)] * 5, B | _lib.EPI_RELU) == "bgemm_kernel<2, -1, -1, false>"
-    assert _bgemm_name(8, [S(64, _lib.PRO_BNRELU)], B | St) == "bgemm_kernel<1, -1, -1, false>"
+    assert _bgemm_name(64, [S(4, _lib.PRO_NONE)] * 5, B | _lib.EPI_RELU) == "bgemm_kernel<2, 0, 17, false>"
+    assert _bgemm_name(8, [S(64, _lib.PRO_BNRELU)], B | St) == "bgemm_kernel<1, 1, 3, false>"
+    assert _bgemm_name(8, [S(64, _lib.PRO_BNRELU)], B | St | A) == "bgemm_kernel<1, -1, -1, false>"
     net = TRUNet(input_size=4, precision="bf16")
     assert net.precision == "bf16" and len(net.state_dict()) == 177
     assert net.set_precision("fp32").precision == "fp32"

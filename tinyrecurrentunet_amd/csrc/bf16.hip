@@ -1029,7 +1029,21 @@ extern "C" int trunet_bf16_gemm(const trunet_bgemm_args* h, void* stream) {
         if (pro == TRUNET_PRO_BNBWD && h->epi == (K | A)) BG_LAUNCH(2, TRUNET_PRO_BNBWD, K | A, true);
         if (pro == TRUNET_PRO_BNBWD && h->epi == 0) BG_LAUNCH(2, TRUNET_PRO_BNBWD, 0, true);
     }
-    // everything else (thin layers, eval-mode forwards, the first conv): flags and modes tested at run time
+    // the thin layers of the training step (first conv 4 -> 64, decoder.5: 128 -> 8 and 8 -> 8): channel guards stay, the
+    // prologue / epilogue are compile-time like above
+    constexpr int R = TRUNET_EPI_RELU;
+    if (!full) {
+        if (nrt_all == 1) {
+            if (pro == TRUNET_PRO_BNRELU && h->epi == (B | S)) BG_LAUNCH(1, TRUNET_PRO_BNRELU, B | S, false);
+            if (pro == TRUNET_PRO_BNRELU && h->epi == B) BG_LAUNCH(1, TRUNET_PRO_BNRELU, B, false);
+            if (pro == TRUNET_PRO_NONE && h->epi == (K | S)) BG_LAUNCH(1, TRUNET_PRO_NONE, K | S, false);
+        } else {
+            if (pro == TRUNET_PRO_NONE && h->epi == (B | R)) BG_LAUNCH(2, TRUNET_PRO_NONE, B | R, false);
+            if (pro == TRUNET_PRO_BNBWD && h->epi == (K | S)) BG_LAUNCH(2, TRUNET_PRO_BNBWD, K | S, false);
+            if (pro == TRUNET_PRO_BNBWD && h->epi == 0) BG_LAUNCH(2, TRUNET_PRO_BNBWD, 0, false);
+        }
+    }
+    // everything else (eval-mode forwards, other shapes): flags and modes tested at run time
     if (nrt_all == 1) BG_LAUNCH(1, -1, -1, false);
     BG_LAUNCH(2, -1, -1, false);
 #undef BG_LAUNCH

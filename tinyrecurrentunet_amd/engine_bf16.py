@@ -75,6 +75,11 @@ def _bgemm_name(M, segs, epi):
            (PRO_BNBWD, 0)}
     if full and M > 32 and (pro, epi) in hot:
         return "bgemm_kernel<2, %d, %d, true>" % (pro, epi)
+    R = EPI_RELU
+    thin1 = {(PRO_BNRELU, B | S), (PRO_BNRELU, B), (PRO_NONE, K | S)}
+    thin2 = {(PRO_NONE, B | R), (PRO_BNBWD, K | S), (PRO_BNBWD, 0)}
+    if not full and (pro, epi) in (thin1 if M <= 32 else thin2):
+        return "bgemm_kernel<%d, %d, %d, false>" % (1 if M <= 32 else 2, pro, epi)
     return "bgemm_kernel<%d, -1, -1, false>" % (1 if M <= 32 else 2)
 
 
