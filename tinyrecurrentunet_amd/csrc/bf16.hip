@@ -486,8 +486,6 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
 
     struct Stage { u32x4 dy[BW_MAXD], z[BW_MAXD], s[BW_MAXS]; };
     Stage sa, sb;                                 // two steps of operand loads in flight
-    // what a step needs to know, computed ONCE per step in scalar registers (the three phases of a step used to redo
-    // the divisions: ~1000 scalar instructions per step, the bulk of the kernel's issue slots)
     // a step is (chunk, p); segment positions come from per-piece / per-tile constants hoisted out of the loop (strides are
     // 1 or 2: shifts, no integer division -- the three phases of a step used to redo ~16 divisions per step, ~1000 scalar
     // instructions, the bulk of the kernel's issue slots)
@@ -661,8 +659,8 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
         }
     };
 
-    // rows of dz beyond moct that a 32-row tile still reads (M not a multiple of 32) and source octets beyond a segment's
-    // last one inside its last 32-channel tile must read as zeros: clear both buffers once
+    // octets a 32-row / 32-channel tile reads beyond the real ones (M or nchan not a multiple of 32) only feed output rows /
+    // columns that are discarded; both buffers are cleared once so that those reads are at least deterministic
     {
         const u32x4 z4 = {0u, 0u, 0u, 0u};
         for (int i = tid; i < 2 * img_bytes / 16; i += BW_THREADS) ((u32x4*)smem_)[i] = z4;
