@@ -19,8 +19,21 @@ def step():
     loss.backward(); sched.step(); opt.step()
 for _ in range(3): step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     step()
     torch.cuda.synchronize()
+evs = [e for e in prof.events() if "emcpy" in e.name or "copyBuffer" in e.name]
+print("memcpy-like events:", len(evs))
+import collections
+c = collections.Counter()
+for e in prof.events():
+    if e.name.startswith("hipMemcpy") or "Memcpy" in e.name:
+        par = e.cpu_parent
+        chain = []
+        while par is not None and len(chain) < 4:
+            chain.append(par.name); par = par.cpu_parent
+        c[(e.name, " <- ".join(chain))] += 1
+for k, v in c.most_common(15):
+    print(v, k)
 print(prof.key_averages().table(sort_by="count", row_limit=25, max_name_column_width=40))
 print(prof.key_averages(group_by_stack_n=4).table(sort_by="count", row_limit=40, max_name_column_width=30, max_src_column_width=90))

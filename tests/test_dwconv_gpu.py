@@ -1,0 +1,64 @@
+"""GPU: the fp32 depthwise-conv kernels (trunet_dwconv_fwd / trunet_dwconv_bwd: network.py:33-38 and its autograd) against a
+torch fp64 restatement on random operands whose bias gradient does NOT vanish (the whole-network tests only see it next to a
+BatchNorm, where it is analytically zero): outputs, statistics, data gradient, weight / bias gradient partial sums.  Shapes:
+the three (kernel, stride) pairs of the encoder (sliding-window kernels) at lengths that do not divide into the position
+chunks, with padding frames."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _l2(a, b):
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("K,S,Lin", [(3, 1, 13), (5, 2, 21), (3, 2, 16), (5, 2, 128), (3, 1, 64), (3, 2, 33)])
+def test_dwconv_forward_backward_vs_fp64(K, S, Lin):
+    from tinyrecurrentunet_amd import _lib as L
+    from tinyrecurrentunet_amd._lib import check, ptr
+    lib, st = L.lib(), L.stream()
+    g = torch.Generator(device=DEV)
+    g.manual_seed(100 * K + 10 * S + Lin)
+    rnd = lambda *s: torch.randn(*s, generator=g, device=DEV)
+    N, NP, Cn = 1300, 1536, 24
+    Lout = (Lin + 2 * (K // 2) - K) // S + 1
+    zin = rnd(Cn, Lin, NP)
+    sc, sh, mean = rnd(Cn) * 0.3 + 1, rnd(Cn) * 0.2, rnd(Cn) * 0.1
+    wgt, b = rnd(Cn, 1, K) * 0.5, rnd(Cn) * 0.1
+    zout = torch.empty(Cn, Lout, NP, device=DEV)
+    nparts = lib.trunet_dwconv_nparts(Lout)
+    part = torch.full((nparts * Cn * 2,), float("nan"), device=DEV)
+    check(lib.trunet_dwconv_fwd(ptr(zin), ptr(sc), ptr(sh), ptr(wgt), ptr(b), ptr(zout), ptr(part), Cn, K, S, Lin, Lout, NP, N,
+                                st), "fwd")
+    act = torch.relu(sc[:, None, None] * zin + sh[:, None, None])
+    ref = F.conv1d(act.permute(2, 0, 1).double(), wgt.double(), b.double(), stride=S, padding=K // 2, groups=Cn).permute(1, 2, 0)
+    assert _l2(zout.double(), ref) < 1e-6
+    r = ref[:, :, :N]
+    st_ref = torch.stack([r.sum((1, 2)), (r * r).sum((1, 2))], 1)
+    assert _l2(part.view(nparts, Cn, 2).double().sum(0), st_ref) < 1e-5
+
+    dy, z = rnd(Cn, Lout, NP), rnd(Cn, Lout, NP)
+    ca, cb, cc = rnd(Cn) * 0.5 + 1, rnd(Cn) * 0.1, rnd(Cn) * 0.05
+    din = torch.empty(Cn, Lin, NP, device=DEV)
+    nparts = lib.trunet_dwconv_bwd_nparts(Lin)
+    part = torch.full((nparts * Cn * 2,), float("nan"), device=DEV)
+    wp = torch.full((nparts * Cn * K,), float("nan"), device=DEV)
+    bp = torch.full((nparts * Cn,), float("nan"), device=DEV)
+    check(lib.trunet_dwconv_bwd(ptr(dy), ptr(z), ptr(ca), ptr(cb), ptr(cc), ptr(zin), ptr(sc), ptr(sh), ptr(mean), ptr(wgt),
+                                ptr(din), ptr(part), ptr(wp), ptr(bp), Cn, K, S, Lin, Lout, NP, N, st), "bwd")
+    dz = (ca[:, None, None] * dy + cb[:, None, None] * z + cc[:, None, None]).double()
+    dz[:, :, N:] = 0
+    actn = act.permute(2, 0, 1).double().requires_grad_(True)
+    wd = wgt.double().requires_grad_(True)
+    bd = b.double().requires_grad_(True)
+    F.conv1d(actn, wd, bd, stride=S, padding=K // 2, groups=Cn).backward(dz.permute(2, 0, 1))
+    gin = actn.grad.permute(1, 2, 0) * (act > 0)
+    assert _l2(din.double(), gin) < 1e-6
+    assert _l2(wp.view(nparts, -1).double().sum(0), wd.grad.reshape(-1)) < 1e-5
+    assert _l2(bp.view(nparts, -1).double().sum(0), bd.grad) < 1e-5        # the bias gradient, not vanishing here
+    r = gin[:, :, :N]
+    st_ref = torch.stack([r.sum((1, 2)), (r * (zin[:, :, :N].double() - mean[:, None, None].double())).sum((1, 2))], 1)
+    assert _l2(part.view(nparts, Cn, 2).double().sum(0), st_ref) < 1e-5

@@ -1,6 +1,7 @@
 // Memory-bound stages of the TRU-Net body in the frames-last layout: layout changes, the first
 // (C_in -> 64) strided conv, depthwise convs (forward / backward), BatchNorm statistics -> affine,
 // AdamW.  All are HBM-bound: coalesced 16-byte accesses along the frame axis, one pass per tensor.
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace {
@@ -205,6 +206,172 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(
     for (int k = 0; k < K; ++k) {
         r = block_sum_f64((double)dwk[k], red);
         if (threadIdx.x == 0) w_partials[((size_t)blockIdx.x * C + c) * K + k] = (float)r;
+    }
+}
+
+// ---------------------------------------------------------------- depthwise conv, sliding-window form
+// A thread owns (channel = blockIdx.y, 4 frames, chunk of positions = blockIdx.z) and walks the positions with the K
+// activated inputs (forward) / the three BatchNorm-backward-transformed dz rows a group of S input positions touches
+// (backward) in registers: every tensor row is loaded exactly once (the tap-gather form above re-reads taps through the
+// caches: 19 % more HBM traffic measured).  Statistics rows: partials[DW2_PARTS][C][2], part = chunk * DW2_FB + blockIdx.x.
+constexpr int DW2_FB = 32;                  // blocks over the frame quads (grid-stride)
+constexpr int DW2_CH = 4;                   // position chunks
+constexpr int DW2_PARTS = DW2_FB * DW2_CH;
+
+template <int K, int S>
+__global__ __launch_bounds__(256) void dw2_fwd_kernel(const float* __restrict__ zin, const float* __restrict__ s_in,
+                                                      const float* __restrict__ t_in, const float* __restrict__ w,
+                                                      const float* __restrict__ b, float* __restrict__ zout,
+                                                      float* __restrict__ partials, int C, int Lin, int Lout, int NP, int N) {
+    __shared__ double red[256];
+    const int c = blockIdx.y;
+    const float sc = s_in[c], sh = t_in[c], bb = b[c];
+    float wk[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) wk[k] = w[c * K + k];
+    const int lo0 = (int)(((long long)blockIdx.z * Lout) / DW2_CH), lo1 = (int)(((long long)(blockIdx.z + 1) * Lout) / DW2_CH);
+    double s1 = 0.0, s2 = 0.0;       // per-thread sums in fp64: they feed cancelling BatchNorm expressions
+    for (int qd = blockIdx.x * 256 + threadIdx.x; qd < NP / 4; qd += DW2_FB * 256) {
+        const int n = 4 * qd;
+        const float* src = zin + (size_t)c * Lin * NP + n;
+        float* dst = zout + (size_t)c * Lout * NP + n;
+        auto load_act = [&](int li) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            if (li >= 0 && li < Lin) {
+                const f32x4 v = *(const f32x4*)(src + (size_t)li * NP);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = fmaxf(fmaf(v[e], sc, sh), 0.f);
+            }
+            return a;
+        };
+        f32x4 win[K];                   // win[k] = activated input at li = lo*S + k - K/2
+#pragma unroll
+        for (int k = 0; k < K - S; ++k) win[k + S] = load_act(lo0 * S + k - K / 2);      // pre-shifted: the loop shifts first
+        for (int lo = lo0; lo < lo1; ++lo) {
+#pragma unroll
+            for (int k = 0; k < K - S; ++k) win[k] = win[k + S];
+#pragma unroll
+            for (int k = K - S; k < K; ++k) win[k] = load_act(lo * S + k - K / 2);
+            f32x4 acc = {bb, bb, bb, bb};
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = fmaf(wk[k], win[k][e], acc[e]);
+            *(f32x4*)(dst + (size_t)lo * NP) = acc;
+            float r1 = 0.f, r2 = 0.f;        // the row's four frames in fp32, the running sums in fp64
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e < N) { r1 += acc[e]; r2 = fmaf(acc[e], acc[e], r2); }
+            s1 += (double)r1;
+            s2 += (double)r2;
+        }
+    }
+    const int part = blockIdx.z * DW2_FB + blockIdx.x;
+    const double r1 = block_sum_f64(s1, red);
+    const double r2 = block_sum_f64(s2, red);
+    if (threadIdx.x == 0) {
+        partials[((size_t)part * C + c) * 2 + 0] = (float)r1;
+        partials[((size_t)part * C + c) * 2 + 1] = (float)r2;
+    }
+}
+
+template <int K, int S>
+__global__ __launch_bounds__(256) void dw2_bwd_kernel(
+    const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ ca,
+    const float* __restrict__ cb, const float* __restrict__ cc, const float* __restrict__ zin,
+    const float* __restrict__ s_in, const float* __restrict__ t_in, const float* __restrict__ mean_in,
+    const float* __restrict__ w, float* __restrict__ dy_in, float* __restrict__ partials_in,
+    float* __restrict__ w_partials, float* __restrict__ b_partials, int C, int Lin, int Lout, int NP, int N) {
+    // groups of S input positions li = m*S + e; their taps touch the dz rows m - 1 .. m + 1 (K, S) in {(3,1), (5,2), (3,2)}
+    constexpr int LOMIN = -1, LOMAX = 1, W = 3;
+    static_assert((K == 3 && S == 1) || (K == 5 && S == 2) || (K == 3 && S == 2), "window derived for these shapes");
+    __shared__ double red[256];
+    const int c = blockIdx.y;
+    const float a0 = ca[c], a1 = cb[c], a2 = cc[c];
+    const float sc = s_in[c], sh = t_in[c], mu = mean_in[c];
+    float wk[K];
+    double dwk[K];                   // per-thread sums in fp64 (db and s1 cancel analytically in front of a BatchNorm)
+#pragma unroll
+    for (int k = 0; k < K; ++k) { wk[k] = w[c * K + k]; dwk[k] = 0.0; }
+    double db = 0.0, s1 = 0.0, s2 = 0.0;
+    const int G = (Lin + S - 1) / S;
+    const int m0 = (int)(((long long)blockIdx.z * G) / DW2_CH), m1 = (int)(((long long)(blockIdx.z + 1) * G) / DW2_CH);
+    for (int qd = blockIdx.x * 256 + threadIdx.x; qd < NP / 4; qd += DW2_FB * 256) {
+        const int n = 4 * qd;
+        const float* pdy = dy + (size_t)c * Lout * NP + n;
+        const float* pz = z + (size_t)c * Lout * NP + n;
+        const float* pin = zin + (size_t)c * Lin * NP + n;
+        float* pout = dy_in + (size_t)c * Lin * NP + n;
+        auto load_dz = [&](int lo) {
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+            if (lo >= 0 && lo < Lout) {
+                const f32x4 dv = *(const f32x4*)(pdy + (size_t)lo * NP);
+                const f32x4 zv = *(const f32x4*)(pz + (size_t)lo * NP);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = (n + e < N) ? fmaf(a0, dv[e], fmaf(a1, zv[e], a2)) : 0.f;
+            }
+            return d;
+        };
+        f32x4 dzw[W];                   // dzw[i] = dz row m + LOMIN + i
+#pragma unroll
+        for (int i = 1; i < W; ++i) dzw[i] = load_dz(m0 + LOMIN + i - 1);                // pre-shifted
+        for (int m = m0; m < m1; ++m) {
+#pragma unroll
+            for (int i = 0; i < W - 1; ++i) dzw[i] = dzw[i + 1];
+            dzw[W - 1] = load_dz(m + LOMAX);
+#pragma unroll
+            for (int e = 0; e < S; ++e) {
+                const int li = m * S + e;
+                if (li >= Lin) continue;
+                const f32x4 zi = *(const f32x4*)(pin + (size_t)li * NP);
+                f32x4 act, g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) act[j] = fmaxf(fmaf(zi[j], sc, sh), 0.f);
+                // the four frames of a row are summed in fp32, the running sums are fp64
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    constexpr int half = K / 2;
+                    const int num = e + half - k;                        // relative to m*S; compile-time after unrolling
+                    if (((num % S) + S) % S != 0) continue;
+                    const int lo_rel = (num >= 0) ? num / S : -((-num) / S);
+                    const int wi = lo_rel - LOMIN;
+                    float rw = 0.f, rb = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float dzv = dzw[wi][j];
+                        g[j] = fmaf(wk[k], dzv, g[j]);
+                        rw = fmaf(dzv, act[j], rw);
+                        rb += dzv;
+                    }
+                    dwk[k] += (double)rw;
+                    if (k == half) db += (double)rb;                      // e == 0 here: every dz row counted once
+                }
+                f32x4 o;
+                float r1 = 0.f, r2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[j] = (act[j] > 0.f) ? g[j] : 0.f;
+                    r1 += o[j];
+                    r2 = fmaf(o[j], zi[j] - mu, r2);
+                }
+                s1 += (double)r1;
+                s2 += (double)r2;
+                *(f32x4*)(pout + (size_t)li * NP) = o;
+            }
+        }
+    }
+    const int part = blockIdx.z * DW2_FB + blockIdx.x;
+    double r;
+    r = block_sum_f64(s1, red);
+    if (threadIdx.x == 0) partials_in[((size_t)part * C + c) * 2 + 0] = (float)r;
+    r = block_sum_f64(s2, red);
+    if (threadIdx.x == 0) partials_in[((size_t)part * C + c) * 2 + 1] = (float)r;
+    r = block_sum_f64(db, red);
+    if (threadIdx.x == 0) b_partials[(size_t)part * C + c] = (float)r;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        r = block_sum_f64(dwk[k], red);
+        if (threadIdx.x == 0) w_partials[((size_t)part * C + c) * K + k] = (float)r;
     }
 }
 
@@ -623,14 +790,31 @@ extern "C" int trunet_conv_first_fwd(const float* x, const float* w, const float
     return trunet_launch_status();
 }
 
-extern "C" int trunet_dwconv_nparts(int Lout) { (void)Lout; return DW_PARTS; }
-extern "C" int trunet_dwconv_bwd_nparts(int Lin) { (void)Lin; return DW_PARTS; }
+// TRUNET_DW_GATHER=1: the tap-gather kernels for every shape (A/B measurements)
+static bool dw_gather_forced() {
+    static const bool v = [] { const char* e = getenv("TRUNET_DW_GATHER"); return e && e[0] == '1'; }();
+    return v;
+}
+
+extern "C" int trunet_dwconv_nparts(int Lout) { (void)Lout; return DW2_PARTS; }
+extern "C" int trunet_dwconv_bwd_nparts(int Lin) { (void)Lin; return DW2_PARTS; }
 
 extern "C" int trunet_dwconv_fwd(const float* zin, const float* s_in, const float* t_in, const float* w, const float* b,
                                  float* zout, float* partials, int C, int K, int S, int Lin, int Lout, int NP, int N,
                                  void* stream) {
     if (!zin || !s_in || !t_in || !w || !b || !zout || !partials || (NP % 128)) return TRUNET_EINVAL;
-    dim3 grid(DW_PARTS, C);
+    if (!dw_gather_forced() && Lout == (Lin + 2 * (K / 2) - K) / S + 1 &&
+        ((K == 3 && S == 1) || (K == 5 && S == 2) || (K == 3 && S == 2))) {
+        const dim3 g2(DW2_FB, C, DW2_CH);
+#define DW2_FWD(KK, SS) hipLaunchKernelGGL((dw2_fwd_kernel<KK, SS>), g2, dim3(256), 0, ST, zin, s_in, t_in, w, b, zout, partials, C, \
+                                           Lin, Lout, NP, N)
+        if (K == 3 && S == 1) DW2_FWD(3, 1);
+        else if (K == 5) DW2_FWD(5, 2);
+        else DW2_FWD(3, 2);
+#undef DW2_FWD
+        return trunet_launch_status();
+    }
+    dim3 grid(DW2_PARTS, C);            // other shapes: the tap-gather form, one statistics row per block as well
     if (K == 3) hipLaunchKernelGGL(dwconv_fwd_kernel<3>, grid, dim3(256), 0, ST, zin, s_in, t_in, w, b, zout, partials, C, S, Lin, Lout, NP, N);
     else if (K == 5) hipLaunchKernelGGL(dwconv_fwd_kernel<5>, grid, dim3(256), 0, ST, zin, s_in, t_in, w, b, zout, partials, C, S, Lin, Lout, NP, N);
     else return TRUNET_ENOTSUP;
@@ -644,7 +828,18 @@ extern "C" int trunet_dwconv_bwd(const float* dy, const float* z, const float* c
     if (!dy || !z || !ca || !cb || !cc || !zin || !s_in || !t_in || !mean_in || !w || !dy_in || !partials_in ||
         !w_partials || !b_partials || (NP % 128))
         return TRUNET_EINVAL;
-    dim3 grid(DW_PARTS, C);
+    if (!dw_gather_forced() && Lout == (Lin + 2 * (K / 2) - K) / S + 1 &&
+        ((K == 3 && S == 1) || (K == 5 && S == 2) || (K == 3 && S == 2))) {
+        const dim3 g2(DW2_FB, C, DW2_CH);
+#define DW2_BWD(KK, SS) hipLaunchKernelGGL((dw2_bwd_kernel<KK, SS>), g2, dim3(256), 0, ST, dy, z, ca, cb, cc, zin, s_in, t_in,   \
+                                           mean_in, w, dy_in, partials_in, w_partials, b_partials, C, Lin, Lout, NP, N)
+        if (K == 3 && S == 1) DW2_BWD(3, 1);
+        else if (K == 5) DW2_BWD(5, 2);
+        else DW2_BWD(3, 2);
+#undef DW2_BWD
+        return trunet_launch_status();
+    }
+    dim3 grid(DW2_PARTS, C);
     if (K == 3) hipLaunchKernelGGL(dwconv_bwd_kernel<3>, grid, dim3(256), 0, ST, dy, z, ca, cb, cc, zin, s_in, t_in, mean_in, w, dy_in, partials_in, w_partials, b_partials, C, S, Lin, Lout, NP, N);
     else if (K == 5) hipLaunchKernelGGL(dwconv_bwd_kernel<5>, grid, dim3(256), 0, ST, dy, z, ca, cb, cc, zin, s_in, t_in, mean_in, w, dy_in, partials_in, w_partials, b_partials, C, S, Lin, Lout, NP, N);
     else return TRUNET_ENOTSUP;
