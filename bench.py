@@ -361,14 +361,21 @@ def main():
         name = max(agg, key=lambda k: agg[k][0])
         tot_ms, flops, n = agg[name]
         ach = flops / (tot_ms * 1e-3) / 1e12
+        # rank the bf16 family by kernel (all template instances of one kernel together), report the dominant instance
+        if args.dtype == "bf16":
+            fam = {}
+            for k, v in agg.items():
+                fam.setdefault(k.split("<")[0], []).append((v[0], k))
+            top = max(fam.values(), key=lambda l: sum(t for t, _ in l))
+            name = max(top)[1]
+            tot_ms, flops, n = agg[name]
         # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
         # separate runs, gfx950 correction 2*FETCH + WRITE; scripts/collect_profile.sh + summarize_profile.py): the
         # newest profiles/*_pmc_traffic.json that knows the kernel; null when none does or the workload is not the default
         traffic, traffic_src, traffic_stale = None, None, None
         try:
             import glob
-            if not (args.tgru or args.no_stft_loss or args.no_pcen or args.batch != 64 or args.seconds != 4.0
-                    or args.dtype != "f32"):
+            if not (args.tgru or args.no_stft_loss or args.no_pcen or args.batch != 64 or args.seconds != 4.0):
                 for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")),
                                  key=os.path.getmtime, reverse=True):
                     doc = json.load(open(fn))
@@ -380,14 +387,6 @@ def main():
                         break
         except Exception:
             traffic = None
-        # rank the bf16 family by kernel (all template instances of one kernel together), report the dominant instance
-        if args.dtype == "bf16":
-            fam = {}
-            for k, v in agg.items():
-                fam.setdefault(k.split("<")[0], []).append((v[0], k))
-            top = max(fam.values(), key=lambda l: sum(t for t, _ in l))
-            name = max(top)[1]
-            tot_ms, flops, n = agg[name]
         bf16_kernel = name.startswith(("bgemm_kernel", "bwgrad_kernel", "bdw_"))
         if bf16_kernel:
             # the bf16 family is an HBM stream: `flops` holds the ALGORITHMIC BYTES of its launches (every operand row
@@ -395,7 +394,10 @@ def main():
             gbs = flops / (tot_ms * 1e-3) / 1e9
             bytes_per_frame = HBM_BYTES_PER_FRAME_STEP / 2
             roof = {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                    "frac": round(gbs / PEAK_HBM_GBPS, 4), "traffic": None, "launches_per_step": n,
+                    "frac": round(gbs / PEAK_HBM_GBPS, 4), "traffic": traffic,
+                    "traffic_GBps": (round(traffic / (tot_ms / n * 1e-3) / 1e9, 1) if traffic else None),
+                    "traffic_source": traffic_src, "traffic_measured_on_other_kernel_source": traffic_stale,
+                    "launches_per_step": n,
                     "avg_launch_ms": round(tot_ms / n, 4), "algorithmic_bytes_per_launch": round(flops / n),
                     "kernel_ms_per_step": {k: round(v[0], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])},
                     "step_hbm_GBps_layer_model": round(value / world * bytes_per_frame / 1e9, 1),
