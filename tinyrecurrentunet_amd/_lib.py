@@ -8,7 +8,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libtrunet_hip.so")
+# TRUNET_HIP_LIB: another build of the same library (diagnostic / A-B builds under scripts/dbg); default: the in-tree one
+LIB_PATH = os.environ.get("TRUNET_HIP_LIB") or os.path.join(_HERE, "csrc", "libtrunet_hip.so")
 
 MAX_SEG = 5
 TRUNET_OK, TRUNET_EINVAL, TRUNET_ELAUNCH, TRUNET_ENOTSUP = 0, -1, -2, -3

@@ -271,7 +271,11 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(const trunet_bgemm_args a
                     u32x2 o;
                     o[0] = bf_pack(val[0], val[1]);
                     o[1] = bf_pack(val[2], val[3]);
+#ifdef TRUNET_BG_NT
+                    __builtin_nontemporal_store(o, (u32x2*)a.out + eidx);
+#else
                     ((u32x2*)a.out)[eidx] = o;
+#endif
                     if (has(TRUNET_EPI_STATS)) {
                         const float rv[4] = {bf_lo(o[0]), bf_hi(o[0]), bf_lo(o[1]), bf_hi(o[1])};
                         const bool fin = nn < a.N;
@@ -738,6 +742,16 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
 // ---------------------------------------------------------------------------------------------------------------------
 // depthwise conv, octet layout.  A thread owns (octet = blockIdx.y, frame, chunk of positions = blockIdx.z) and walks the
 // positions with a sliding window in registers: every input row is loaded once.
+// every row is touched exactly once: non-temporal accesses (same-box A/B: -0.5 ms per step; -DTRUNET_DW_TEMPORAL builds the
+// default-policy form)
+#ifndef TRUNET_DW_TEMPORAL
+#define BDW_LD(p) __builtin_nontemporal_load((const u32x4*)(p))
+#define BDW_ST(p, v) __builtin_nontemporal_store((v), (u32x4*)(p))
+#else
+#define BDW_LD(p) (*(const u32x4*)(p))
+#define BDW_ST(p, v) (*(u32x4*)(p) = (v))
+#endif
+
 template <int NV>
 __device__ __forceinline__ void block_reduce_store(float (&v)[NV], float* smem /* [4][NV] */, float* dst, int stride) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -780,7 +794,7 @@ __global__ __launch_bounds__(256) void bdw_fwd_kernel(const u32x4* __restrict__ 
     auto load_act = [&](int li, float (&act)[8]) {
         if (li >= 0 && li < Lin) {
             float v[8];
-            bf_unpack8(src[(size_t)li * NP], v);
+            bf_unpack8(BDW_LD(src + (size_t)li * NP), v);
 #pragma unroll
             for (int j = 0; j < 8; ++j) act[j] = fmaxf(fmaf(v[j], sc[j], sh[j]), 0.f);
         } else {
@@ -806,7 +820,7 @@ __global__ __launch_bounds__(256) void bdw_fwd_kernel(const u32x4* __restrict__ 
             for (int k = 0; k < K; ++k) acc[j] = fmaf(wk[j][k], win[k][j], acc[j]);
         }
         const u32x4 o = bf_pack8(acc);
-        dst[(size_t)lo * NP] = o;
+        BDW_ST(dst + (size_t)lo * NP, o);
         if (n < N) {
             float r[8];
             bf_unpack8(o, r);
@@ -859,8 +873,8 @@ __global__ __launch_bounds__(256) void bdw_bwd_kernel(const u32x4* __restrict__ 
     auto load_dz = [&](int lo, float (&d)[8]) {
         if (lo >= 0 && lo < Lout && fin) {
             float dv[8], zv[8];
-            bf_unpack8(pdy[(size_t)lo * NP], dv);
-            bf_unpack8(pz[(size_t)lo * NP], zv);
+            bf_unpack8(BDW_LD(pdy + (size_t)lo * NP), dv);
+            bf_unpack8(BDW_LD(pz + (size_t)lo * NP), zv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) d[j] = fmaf(a0[j], dv[j], fmaf(a1[j], zv[j], a2[j]));
         } else {
@@ -882,7 +896,7 @@ __global__ __launch_bounds__(256) void bdw_bwd_kernel(const u32x4* __restrict__ 
             const int li = m * S + e;
             if (li >= Lin) continue;
             float zi[8], act[8], g[8];
-            bf_unpack8(pin[(size_t)li * NP], zi);
+            bf_unpack8(BDW_LD(pin + (size_t)li * NP), zi);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { act[j] = fmaxf(fmaf(zi[j], sc[j], sh[j]), 0.f); g[j] = 0.f; }
 #pragma unroll
@@ -904,7 +918,7 @@ __global__ __launch_bounds__(256) void bdw_bwd_kernel(const u32x4* __restrict__ 
 #pragma unroll
             for (int j = 0; j < 8; ++j) ov[j] = (act[j] > 0.f) ? g[j] : 0.f;
             const u32x4 o = bf_pack8(ov);
-            pout[(size_t)li * NP] = o;
+            BDW_ST(pout + (size_t)li * NP, o);
             float r[8];
             bf_unpack8(o, r);
 #pragma unroll

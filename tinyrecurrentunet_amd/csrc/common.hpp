@@ -10,6 +10,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define TRUNET_NUM_CU 256
 
+// cache policy of the LDS-DMA operand streams (aux operand of global_load_lds): 0 default, 2 = nt.  A/B build switch.
+#ifndef TRUNET_DMA_AUX
+#define TRUNET_DMA_AUX 0
+#endif
+
 static inline int trunet_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TRUNET_OK : TRUNET_ELAUNCH;

@@ -112,8 +112,8 @@ __global__ __launch_bounds__(512, 2) void convt_bwd_kernel(const trunet_convt_bw
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const size_t off = ((size_t)row_[i] * Lout + p) * NP + n0 + 4 * lc_[i];
-                    __builtin_amdgcn_global_load_lds(a.dy + off, (ct_lds_ptr_t)(dst + (wave + 4 * i) * 256), 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds(a.z + off, (ct_lds_ptr_t)(zst + (wave + 4 * i) * 256), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(a.dy + off, (ct_lds_ptr_t)(dst + (wave + 4 * i) * 256), 16, 0, TRUNET_DMA_AUX);
+                    __builtin_amdgcn_global_load_lds(a.z + off, (ct_lds_ptr_t)(zst + (wave + 4 * i) * 256), 16, 0, TRUNET_DMA_AUX);
                 }
                 n += 4;
             }
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(512, 2) void convt_bwd_kernel(const trunet_convt_bw
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const size_t off = ((size_t)row_[i] * Lin + sq) * NP + n0 + 4 * lc_[i];
-                    __builtin_amdgcn_global_load_lds(a.src + off, (ct_lds_ptr_t)(sdst + (wave + 4 * i) * 256), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(a.src + off, (ct_lds_ptr_t)(sdst + (wave + 4 * i) * 256), 16, 0, TRUNET_DMA_AUX);
                 }
                 n += 2;
             }

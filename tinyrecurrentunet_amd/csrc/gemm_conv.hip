@@ -152,7 +152,7 @@ __global__ __launch_bounds__(64 * NW, (EPL == 0 || NW == 8) ? 2 : 1) void conv_g
                 const int cch = min(it.cc * KC + row, sg.nchan - 1);      // rows past the segment: finite filler (A = 0)
                 const unsigned off = (unsigned)cch * rstride + (unsigned)col;
                 const float* gp = ((TWO && (i % NSRC)) ? b1 : b0) + off;
-                __builtin_amdgcn_global_load_lds(gp, (lds_ptr_t)(dst + (i % NSRC) * (KC * FT) + g * 256), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(gp, (lds_ptr_t)(dst + (i % NSRC) * (KC * FT) + g * 256), 16, 0, TRUNET_DMA_AUX);
             }
         };
         // in-place prologue on this thread's own pieces of the chunk in `slot` (all reads first, then the math,
@@ -302,7 +302,11 @@ __global__ __launch_bounds__(64 * NW, (EPL == 0 || NW == 8) ? 2 : 1) void conv_g
 #pragma unroll
                     for (int t = 0; t < CT; ++t) vset<CT>(val, t, fmaxf(vget<CT>(val, t), 0.f));
                 }
+#ifdef TRUNET_EPI_NT
+                if (m < a.M) __builtin_nontemporal_store(val, (bvec*)(a.out + off));
+#else
                 if (m < a.M) *(bvec*)(a.out + off) = val;
+#endif
                 if (a.epi & TRUNET_EPI_STATS) {
 #pragma unroll
                     for (int t = 0; t < CT; ++t) {
@@ -827,15 +831,15 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const trunet_wgrad_a
                 for (int i = 0; i < 3; ++i) {
                     if (i < PPW) {
                         const int g = wave + 8 * i;
-                        __builtin_amdgcn_global_load_lds(pd[i] + n0, (lds_ptr_t)(dst + g * 256), 16, 0, 0);
-                        if (TWO) __builtin_amdgcn_global_load_lds(pzr[i] + n0, (lds_ptr_t)(dst + (MA / 8 + g) * 256), 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds(pd[i] + n0, (lds_ptr_t)(dst + g * 256), 16, 0, TRUNET_DMA_AUX);
+                        if (TWO) __builtin_amdgcn_global_load_lds(pzr[i] + n0, (lds_ptr_t)(dst + (MA / 8 + g) * 256), 16, 0, TRUNET_DMA_AUX);
                     }
                 }
 #pragma unroll
                 for (int i = 0; i < 5; ++i) {
                     if (i < SPW) {
                         const int g = wave + 8 * i;
-                        __builtin_amdgcn_global_load_lds(ps[i] + n0, (lds_ptr_t)(dst + (DZR / 8 + g) * 256), 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds(ps[i] + n0, (lds_ptr_t)(dst + (DZR / 8 + g) * 256), 16, 0, TRUNET_DMA_AUX);
                     }
                 }
             };

@@ -76,11 +76,18 @@ __device__ __forceinline__ PSegPos pwb_seg_pos(const trunet_seg& sg, int p) {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t pwb_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
 }
+#ifndef TRUNET_PWB_DMA_AUX
+#define TRUNET_PWB_DMA_AUX TRUNET_DMA_AUX
+#endif
+// cache policy of the epilogue rows (each is touched once per launch): TRUNET_PWB_AUX = 2 is nt.  A/B build switch.
+#ifndef TRUNET_PWB_AUX
+#define TRUNET_PWB_AUX 0
+#endif
 __device__ __forceinline__ float pwb_bload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, TRUNET_PWB_AUX));
 }
 __device__ __forceinline__ void pwb_bstore(__amdgpu_buffer_rsrc_t r, int voff, int soff, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, voff, soff, TRUNET_PWB_AUX);
 }
 
 // wave-uniform values the compiler cannot prove uniform (they pass through per-wave role tables)
@@ -275,14 +282,14 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
 #pragma unroll
                 for (int i = 0; i < PDW; ++i) {
                     const int g = wave + 4 * i;
-                    __builtin_amdgcn_global_load_lds(pd[i] + n0, (lds_ptr_t)(dst + g * 256), 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds(pzr[i] + n0, (lds_ptr_t)(dst + (MA / 8 + g) * 256), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(pd[i] + n0, (lds_ptr_t)(dst + g * 256), 16, 0, TRUNET_PWB_DMA_AUX);
+                    __builtin_amdgcn_global_load_lds(pzr[i] + n0, (lds_ptr_t)(dst + (MA / 8 + g) * 256), 16, 0, TRUNET_PWB_DMA_AUX);
                 }
 #pragma unroll
                 for (int i = 0; i < PSW; ++i) {
                     if (i < SPW) {
                         const int g = wave + 4 * i;
-                        __builtin_amdgcn_global_load_lds(ps[i] + n0, (lds_ptr_t)(dst + (DZR / 8 + g) * 256), 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds(ps[i] + n0, (lds_ptr_t)(dst + (DZR / 8 + g) * 256), 16, 0, TRUNET_PWB_DMA_AUX);
                     }
                 }
             };
