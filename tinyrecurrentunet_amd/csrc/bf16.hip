@@ -51,6 +51,17 @@ __device__ __forceinline__ int butterfly16_index(int c) {
     return ((c & 16) ? 8 : 0) + ((c & 8) ? 4 : 0) + ((c & 4) ? 2 : 0) + ((c & 2) ? 1 : 0);
 }
 
+// A/B switches for the cache policy of the operand streams (default: temporal)
+#ifdef TRUNET_BW_NT
+#define BW_LD(p) __builtin_nontemporal_load(p)
+#else
+#define BW_LD(p) (*(p))
+#endif
+#ifdef TRUNET_BGL_NT
+#define BG_LD(p) __builtin_nontemporal_load(p)
+#else
+#define BG_LD(p) (*(p))
+#endif
 constexpr int BG_GRID = 2 * TRUNET_NUM_CU;      // workgroups of 4 waves, two per CU
 constexpr int BG_MAXKS = 24;                    // k-steps of 16 channels over all segments (5 x 64 channels = 20)
 
@@ -172,8 +183,8 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(const trunet_bgemm_args a
                     for (int cb = 0; cb < BG_NCB; ++cb) {
                         if (FULL) {
                             if (ok) {       // wave-uniform
-                                r0[j][cb] = b0[o + 32 * cb];
-                                if constexpr (TWO) if (mode == TRUNET_PRO_BNBWD) r1[j][cb] = b1[o + 32 * cb];
+                                r0[j][cb] = BG_LD(b0 + o + 32 * cb);
+                                if constexpr (TWO) if (mode == TRUNET_PRO_BNBWD) r1[j][cb] = BG_LD(b1 + o + 32 * cb);
                             }
                         } else {
                             r0[j][cb] = ok ? b0[o + 32 * cb] : z4;
@@ -521,8 +532,8 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
             const int oct = wave + 8 * j;
             if (oct < moct) {
                 const size_t idx = ((size_t)oct * a.a_L + p + a.a_pos_off) * a.NP + n;
-                r.dy[j] = ((const u32x4*)a.a0)[idx];
-                if (two) r.z[j] = ((const u32x4*)a.a1)[idx];
+                r.dy[j] = BW_LD((const u32x4*)a.a0 + idx);
+                if (two) r.z[j] = BW_LD((const u32x4*)a.a1 + idx);
             }
         }
 #pragma unroll
@@ -531,7 +542,7 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
                 const trunet_bseg& sg = a.seg[soct_seg[j]];
                 bool valid; int q;
                 pos(pc_s[j], f.p, valid, q);
-                if (valid) r.s[j] = ((const u32x4*)sg.src0)[((size_t)soct_idx[j] * sg.L + q) * a.NP + n];
+                if (valid) r.s[j] = BW_LD((const u32x4*)sg.src0 + ((size_t)soct_idx[j] * sg.L + q) * a.NP + n);
             }
         }
     };
