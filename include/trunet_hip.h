@@ -415,6 +415,20 @@ typedef struct {
 typedef struct { trunet_bwgrad_args w; trunet_bdgrad_args dg; } trunet_bpwbwd_args;
 int trunet_bf16_pw_bwd_nparts(void);
 int trunet_bf16_pw_bwd(const trunet_bpwbwd_args* h_args, void* stream);
+/* Fused backward of ConvTranspose1d(64 -> 64, K, S) + BatchNorm on octet tensors (autograd of network.py:67,86: decoder.0-4), the
+ * bf16 counterpart of trunet_convt_bwd: one pass over (dy, z, source) with a sliding window of BatchNorm-backward-transformed
+ * dz rows in LDS -> weight gradient W[ci][co][k] and bias gradient (fp32 partial images as trunet_conv_wgrad), the masked data
+ * gradient dsrc[ci][q] of the pointwise BatchNorm's output and its BatchNorm-backward sums
+ * partials[trunet_bf16_convt_bwd_nparts()][64][2] (zero-filled by the call).  wfragT = trunet_bf16_pack_weight(W, ., 64, Co*K, K,
+ * 0, K, {64,..}, {0..K-1}).  Ci = Co = 64, (K, S) in {(3,1), (5,2), (3,2)}, pad = S/2 (else TRUNET_ENOTSUP). */
+typedef struct {
+    int32_t NP, N, Lin, Lout, K, S, pad, Ci, Co, w_numel, b_stride, b_off;
+    const void* dy; const void* z; const float* ca; const float* cb; const float* cc;
+    const void* src; const float* s_scale; const float* s_shift; const float* s_mean;
+    const void* wfragT; void* dsrc; float* partials; float* w_partials; float* b_partials;
+} trunet_bconvt_args;
+int trunet_bf16_convt_bwd_nparts(void);
+int trunet_bf16_convt_bwd(const trunet_bconvt_args* h_args, void* stream);
 /* depthwise conv in the octet layout (network.py:33-38): BN+ReLU prologue on the input, raw bf16 output, fp32 statistics
  * partials[trunet_bf16_dw_nparts(NP, rows)][C][2] (rows = Lout forward, Lin backward); backward: dz = ca dy + cb z + cc, masked
  * data gradient of the input (+ its BatchNorm-backward sums), fp32 partial images w_partials[nparts][C][K],

@@ -689,3 +689,44 @@ def test_bf16_training_tracks_fp32():
     assert f[-1] < 0.6 * f[0] and b[-1] < 0.6 * b[0], (f[0], f[-1], b[0], b[-1])
     assert max(abs(x - y) / x for x, y in zip(f, b)) < 0.06, [round(abs(x - y) / x, 4) for x, y in zip(f, b)]
     assert abs(f[-1] - b[-1]) < 0.02 * f[-1], (f[-1], b[-1])
+
+
+def test_bf16_fused_transposed_conv_backward_matches_separate_launches():
+    """trunet_bf16_convt_bwd against trunet_bf16_wgrad + trunet_bf16_gemm over the tap segments, layer by layer: decoder.4 is
+    the first transposed conv of the backward that takes the fused kernel, so its weight / bias / BatchNorm gradients must be
+    reproduced (the weight-gradient MFMAs run in another order: 2e-5), and the whole gradient vector must stay within the
+    bf16 noise floor of the separate launches (see the pointwise test)."""
+    from tinyrecurrentunet_amd import engine_bf16
+    from tinyrecurrentunet_amd.network import TRUNet
+    g = torch.Generator(device=DEV)
+    g.manual_seed(19)
+    N = 700
+    x = torch.randn(N, 4, 257, generator=g, device=DEV)
+    gout = torch.randn(N, 8, 257, generator=g, device=DEV) / N
+    res = []
+    old = engine_bf16.FUSED_CONVT16
+    try:
+        for fused in (False, True):
+            engine_bf16.FUSED_CONVT16 = fused
+            torch.manual_seed(9)
+            net = TRUNet(input_size=4, precision="bf16").cuda().train()
+            y = net(x)
+            y.backward(gout)
+            res.append({n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None})
+    finally:
+        engine_bf16.FUSED_CONVT16 = old
+    sep, fus = res
+    assert sum(t.numel() for t in fus.values()) == 298592
+    for n in ("decoder.5.LastTrCNN.0.weight", "decoder.5.LastTrCNN.3.weight", "decoder.5.LastTrCNN.1.weight"):
+        assert torch.equal(sep[n], fus[n]), n                      # upstream of the first fused layer: untouched
+    for n in ("decoder.4.TrCNN.3.weight", "decoder.4.TrCNN.3.bias", "decoder.4.TrCNN.4.weight", "decoder.4.TrCNN.4.bias"):
+        e = _l2(fus[n], sep[n]) if sep[n].norm().item() > 1e-6 else (fus[n] - sep[n]).norm().item()
+        assert e < 5e-5, (n, e)
+    bad = []
+    for n, a in sep.items():
+        b = fus[n]
+        sib = n[:-6] + "bias" if n.endswith(".1.weight") else (n[:-4] + "weight" if n.endswith("bias") else n)
+        scale = max(a.norm().item(), sep[sib].norm().item() if sib in sep else 0.0)
+        if (a - b).norm().item() > 2e-2 * scale:
+            bad.append((n, (a - b).norm().item(), scale))
+    assert not bad, bad

@@ -94,6 +94,13 @@ class BPwBwdArgs(C.Structure):
     _fields_ = [("w", BWgradArgs), ("dg", BDgradArgs)]
 
 
+class BConvtArgs(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("NP", "N", "Lin", "Lout", "K", "S", "pad", "Ci", "Co", "w_numel", "b_stride",
+                                         "b_off")] + \
+               [(n, _fp) for n in ("dy", "z", "ca", "cb", "cc", "src", "s_scale", "s_shift", "s_mean", "wfragT", "dsrc",
+                                   "partials", "w_partials", "b_partials")]
+
+
 _lib = None
 
 
@@ -173,6 +180,8 @@ def _declare(L):
         "trunet_bf16_wgrad": [C.POINTER(BWgradArgs), p],
         "trunet_bf16_pw_bwd_nparts": [],
         "trunet_bf16_pw_bwd": [C.POINTER(BPwBwdArgs), p],
+        "trunet_bf16_convt_bwd_nparts": [],
+        "trunet_bf16_convt_bwd": [C.POINTER(BConvtArgs), p],
         "trunet_bf16_dw_nparts": [i, i],
         "trunet_bf16_dwconv_fwd": [p, p, p, p, p, p, p, i, i, i, i, i, i, i, p],
         "trunet_bf16_dwconv_bwd": [p] * 14 + [i] * 7 + [p],

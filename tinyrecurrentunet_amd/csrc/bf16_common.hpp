@@ -1,0 +1,64 @@
+// Shared device helpers of the bf16 family (bf16.hip, bf16_convt.hip): bf16 pack / unpack, the 16-value butterfly reduction,
+// the [octet][frame][8] LDS image and its transposed fragment reads.
+#pragma once
+#include "common.hpp"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+__device__ __forceinline__ unsigned bf_pack(float lo, float hi) {      // round to nearest even (v_cvt_pk_bf16_f32)
+    const __bf16 a = (__bf16)lo, b = (__bf16)hi;
+    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+__device__ __forceinline__ void bf_unpack8(const u32x4 v, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = bf_lo(v[i]); f[2 * i + 1] = bf_hi(v[i]); }
+}
+__device__ __forceinline__ u32x4 bf_pack8(const float (&f)[8]) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = bf_pack(f[2 * i], f[2 * i + 1]);
+    return v;
+}
+
+// sum each of 16 per-lane values over the 32 lanes of a half-wave; lane c returns the total of value butterfly16_index(c)
+// (16 cross-lane exchanges instead of 80, and ONE live register instead of 16)
+__device__ __forceinline__ float butterfly16(const float (&x)[16], int c) {
+    float y8[8], y4[4], y2[2];
+    const bool b16 = c & 16, b8 = c & 8, b4 = c & 4, b2 = c & 2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) y8[i] = (b16 ? x[i + 8] : x[i]) + __shfl_xor(b16 ? x[i] : x[i + 8], 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y4[i] = (b8 ? y8[i + 4] : y8[i]) + __shfl_xor(b8 ? y8[i] : y8[i + 4], 8);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) y2[i] = (b4 ? y4[i + 2] : y4[i]) + __shfl_xor(b4 ? y4[i] : y4[i + 2], 4);
+    const float y1 = (b2 ? y2[1] : y2[0]) + __shfl_xor(b2 ? y2[0] : y2[1], 2);
+    return y1 + __shfl_xor(y1, 1);
+}
+__device__ __forceinline__ int butterfly16_index(int c) {
+    return ((c & 16) ? 8 : 0) + ((c & 8) ? 4 : 0) + ((c & 4) ? 2 : 0) + ((c & 2) ? 1 : 0);
+}
+
+constexpr int BW_F = 64;                         // frames per step
+constexpr int BW_OS = BW_F * 16 + 64;            // LDS bytes between octets
+
+__device__ __forceinline__ u32x2 lds_tr16(const unsigned char* p) {
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+    return __builtin_bit_cast(u32x2, v);
+}
+// fragment (rows = 32 channels starting at octet oct0, k = 16 frames starting at f0) of an [octet][frame][8] image
+__device__ __forceinline__ bf16x8 lds_frag(const unsigned char* img, int oct0, int f0, int lane) {
+    const int G = lane >> 4, i = lane & 15;
+    const unsigned char* p = img + (oct0 + 2 * (G & 1) + ((i & 3) >> 1)) * BW_OS + (f0 + 8 * (G >> 1) + (i >> 2)) * 16 + 8 * (i & 1);
+    const u32x2 lo = lds_tr16(p), hi = lds_tr16(p + 64);
+    const u32x4 f = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8, f);
+}
+
+}  // namespace

@@ -19,7 +19,7 @@ from . import engine as E
 import os
 
 from ._lib import (DG_ACCUM, DG_MASK, DG_STATS, DG_STORE, EPI_ACCUM, EPI_BIAS, EPI_MASK, EPI_RELU, EPI_STATS, PRO_BNBWD,
-                   PRO_BNRELU, PRO_NONE, BGemmArgs, BPwBwdArgs, BSeg, BWgradArgs, check, ptr, ptr16)
+                   PRO_BNRELU, PRO_NONE, BConvtArgs, BGemmArgs, BPwBwdArgs, BSeg, BWgradArgs, check, ptr, ptr16)
 from .engine import BN_MOM, F_BINS, FRAME_PAD, Act, TRUNetEngine, _Timed, _seg_positions, ceil_to
 
 BF16 = torch.bfloat16
@@ -28,6 +28,9 @@ BF16 = torch.bfloat16
 # pass over dy, z, sources) instead of trunet_bf16_wgrad + one trunet_bf16_gemm per source; TRUNET_BF16_FUSED_PWBWD=0 keeps the
 # separate launches (A/B measurements, and the reference the fused kernel is tested against bit for bit).
 FUSED_PWBWD16 = os.environ.get("TRUNET_BF16_FUSED_PWBWD", "1") != "0"
+# Backward of the 64 -> 64 transposed convs (decoder.0-4): one fused launch (trunet_bf16_convt_bwd) instead of trunet_bf16_wgrad
+# + trunet_bf16_gemm over the tap segments; TRUNET_BF16_FUSED_CONVT=0 keeps the separate launches.
+FUSED_CONVT16 = os.environ.get("TRUNET_BF16_FUSED_CONVT", "1") != "0"
 
 
 def bseg(src0, nchan, Ln, pos_mul=1, pos_off=0, pos_div=1, woff=0, mode=PRO_NONE, src1=None, c0=None, c1=None, c2=None):
@@ -400,19 +403,59 @@ class TRUNetEngineBF16(TRUNetEngine):
             self._bn_bwd(w, bn, nparts, grads, part_name=pname)
         return True
 
+    def _convt_bwd16(self, w, N, NP, ct, a_pw, Lo, dy, z, bn, dy_pw, grads):
+        """trunet_bf16_convt_bwd: weight / bias gradient, the masked data gradient at the pointwise BatchNorm's output and its
+        BatchNorm-backward sums in one pass over (dy, z, source).  False when the kernel does not take the layer."""
+        lib, st = L.lib(), L.stream()
+        k, s_, pad = ct.kernel_size[0], ct.stride[0], ct.padding[0]
+        Ci, Co = ct.in_channels, ct.out_channels
+        if Ci != 64 or Co != 64 or (k, s_) not in ((3, 1), (5, 2), (3, 2)) or pad != s_ // 2:
+            return False
+        nks = 4 * k
+        wfragT = w.flat("wfragT", 2 * nks * 64 * 8, dtype=BF16)
+        nch = (C.c_int32 * k)(*([Co] * k))
+        wof = (C.c_int32 * k)(*range(k))
+        rc = lib.trunet_bf16_pack_weight(ptr(ct.weight.data), ptr16(wfragT), Ci, Co * k, k, 0, k, nch, wof, st)
+        if rc != nks:
+            raise L.TrunetHipError("trunet_bf16_pack_weight (convT W^T): code %d" % rc)
+        a = BConvtArgs()
+        a.NP, a.N, a.Lin, a.Lout, a.K, a.S, a.pad, a.Ci, a.Co = NP, N, a_pw.L, Lo, k, s_, pad, Ci, Co
+        a.dy, a.z = ptr16(dy), ptr16(z)
+        a.ca, a.cb, a.cc = ptr(bn.ca), ptr(bn.cb), ptr(bn.cc)
+        a.src, a.s_scale, a.s_shift, a.s_mean = ptr16(a_pw.t), ptr(a_pw.bn.scale), ptr(a_pw.bn.shift), ptr(a_pw.bn.mean)
+        nparts = lib.trunet_bf16_convt_bwd_nparts()
+        part = w.flat("ct16_partials", nparts * Ci * 2)
+        a.wfragT, a.dsrc, a.partials = ptr16(wfragT), ptr16(dy_pw), ptr(part)
+        a.w_numel = self._wg_total
+        a.w_partials, a.b_partials = self._wg_slot(ct.weight), self._wg_slot(ct.bias)
+        a.b_stride, a.b_off = self._wg_total, 0
+        if E.PROFILE is not None:
+            by = 2 * (2 * Co * Lo + 2 * Ci * a_pw.L)          # dy, z rows once; source row in, its gradient out
+            with _Timed("bconvt_bwd_kernel<%d, %d>" % (k, s_), float(by) * N, "L%d" % a_pw.L):
+                rc = lib.trunet_bf16_convt_bwd(a, st)
+        else:
+            rc = lib.trunet_bf16_convt_bwd(a, st)
+        if rc == L.TRUNET_ENOTSUP:
+            return False
+        check(rc, "bf16_convt_bwd")
+        self._bn_bwd(w, a_pw.bn, nparts, grads, part_name="ct16_partials")
+        return True
+
     def _bwd_tr16(self, w, N, NP, ct, pw, a_pw, Lo, up, x1, x1_mask, skip, left, dy_x1, g_skip, dy_pw_name, grads):
         """FirstTrCNN / TrCNN / LastTrCNN (network.py:60-120): transposed conv, then the pointwise conv over [x1 | skip]"""
         dy, z, bn = up
         k, s_, pad = ct.kernel_size[0], ct.stride[0], ct.padding[0]
         Ci, Co = ct.in_channels, ct.out_channels
         dy_pw = self._get16(w, dy_pw_name, Ci, a_pw.L, NP)
-        self._wgrad16(w, N=N, NP=NP, P=Lo, M=Co, dz=dy, dz1=z, dz_L=Lo, dz_bn=bn, W=ct.weight, ldw_m=k, ldw_c=Co * k,
-                      segs=[a_pw.seg(pos_off=pad - kk, woff=kk, pos_div=s_) for kk in range(k)], grads=grads, bias=ct.bias)
-        segs = [self._dz_seg16(dy, z, bn, Co, Lo, pos_mul=s_, pos_off=kk - pad, woff=kk) for kk in range(k)]
-        nparts = self._gemm16(w, N=N, NP=NP, P=a_pw.L, M=Ci, out=dy_pw, out_L=a_pw.L, W=ct.weight.data, ldw_m=Co * k,
-                              ldw_c=k, segs=segs, zmask=a_pw.t, e0=a_pw.bn.scale, e1=a_pw.bn.shift, e2=a_pw.bn.mean,
-                              stats=Ci)
-        self._bn_bwd(w, a_pw.bn, nparts, grads)
+        if not (FUSED_CONVT16 and bn is not None and self._convt_bwd16(w, N, NP, ct, a_pw, Lo, dy, z, bn, dy_pw, grads)):
+            self._wgrad16(w, N=N, NP=NP, P=Lo, M=Co, dz=dy, dz1=z, dz_L=Lo, dz_bn=bn, W=ct.weight, ldw_m=k, ldw_c=Co * k,
+                          segs=[a_pw.seg(pos_off=pad - kk, woff=kk, pos_div=s_) for kk in range(k)], grads=grads,
+                          bias=ct.bias)
+            segs = [self._dz_seg16(dy, z, bn, Co, Lo, pos_mul=s_, pos_off=kk - pad, woff=kk) for kk in range(k)]
+            nparts = self._gemm16(w, N=N, NP=NP, P=a_pw.L, M=Ci, out=dy_pw, out_L=a_pw.L, W=ct.weight.data, ldw_m=Co * k,
+                                  ldw_c=k, segs=segs, zmask=a_pw.t, e0=a_pw.bn.scale, e1=a_pw.bn.shift, e2=a_pw.bn.mean,
+                                  stats=Ci)
+            self._bn_bwd(w, a_pw.bn, nparts, grads)
         Lp = a_pw.L
         srcs = [x1.seg(pos_off=-left, woff=0)] + ([skip.seg(woff=x1.C)] if skip is not None else [])
         p0, p1 = max(0, left), min(Lp, x1.L + left)
