@@ -627,30 +627,35 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
     }
     __syncthreads();
 
-    unsigned char* buf0 = smem_;
-    unsigned char* buf1 = smem_ + img_bytes;
+    // BW_DEPTH steps of operand loads in flight in registers (the waves are parked on memory latency 59 % of the time at
+    // depth 2); LDS stays double-buffered: buffer (step & 1)
+#ifndef TRUNET_BW_DEPTH
+#define TRUNET_BW_DEPTH 2
+#endif
+    constexpr int DEPTH = TRUNET_BW_DEPTH;
+    static_assert(DEPTH == 2 || DEPTH == 3, "stages are named");
+    Stage sc;
     Info nx;                                      // the next step to request: advanced incrementally (p fastest)
     nx.chunk = s_begin / a.P;
     nx.p = a.p_begin + (s_begin - nx.chunk * a.P);
     auto advance = [&](Info& f) { if (++f.p == a.p_begin + a.P) { f.p = a.p_begin; ++f.chunk; } };
-    Info fa = nx, fb = nx;
+    Info fa = nx, fb = nx, fc = nx;
     if (s_begin < s_end) { issue(fa, sa); advance(nx); }
     if (s_begin + 1 < s_end) { fb = nx; issue(fb, sb); advance(nx); }
-    for (int st = s_begin; st < s_end; st += 2) {
-        store(fa, buf0, sa);
-        const Info fa_cur = fa;
-        if (st + 2 < s_end) { fa = nx; issue(fa, sa); advance(nx); }
+    if (DEPTH == 3 && s_begin + 2 < s_end) { fc = nx; issue(fc, sc); advance(nx); }
+    auto step = [&](int st, Info& f, Stage& r) {
+        unsigned char* buf = smem_ + ((st - s_begin) & 1) * img_bytes;
+        store(f, buf, r);
+        const Info cur = f;
+        if (st + DEPTH < s_end) { f = nx; issue(f, r); advance(nx); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        mma(fa_cur, buf0);
-        if (st + 1 < s_end) {
-            store(fb, buf1, sb);
-            const Info fb_cur = fb;
-            if (st + 3 < s_end) { fb = nx; issue(fb, sb); advance(nx); }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            mma(fb_cur, buf1);
-        }
+        mma(cur, buf);
+    };
+    for (int st = s_begin; st < s_end; st += DEPTH) {
+        step(st, fa, sa);
+        if (st + 1 < s_end) step(st + 1, fb, sb);
+        if (DEPTH == 3 && st + 2 < s_end) step(st + 2, fc, sc);
     }
 
     // ---- partial image of dW (rows m = dz channel, columns c = source channel) and db
