@@ -417,7 +417,7 @@ def test_bf16_kernel_name_mirror_and_precision_switch():
         def __init__(self, nchan, mode):
             self.nchan, self.mode = nchan, mode
     B, St, A, K = _lib.EPI_BIAS, _lib.EPI_STATS, _lib.EPI_ACCUM, _lib.EPI_MASK
-    assert _bgemm_name(128, [S(128, _lib.PRO_BNRELU)], B | St) == "bgemm_kernel<2, 1, 3, true>"
+    assert _bgemm_name(128, [S(128, _lib.PRO_BNRELU)], B | St) == "bgemm_kernel<4, 1, 3, true>"
     assert _bgemm_name(64, [S(64, _lib.PRO_BNRELU), S(128, _lib.PRO_NONE)], B | St) == "bgemm_kernel<2, 1, 3, true>"
     assert _bgemm_name(128, [S(64, _lib.PRO_BNBWD)], K | St | A) == "bgemm_kernel<2, 2, 14, true>"
     assert _bgemm_name(64, [S(4, _lib.PRO_NONE)] * 5, B | _lib.EPI_RELU) == "bgemm_kernel<2, 0, 17, false>"

@@ -76,6 +76,8 @@ def _bgemm_name(M, segs, epi):
     B, S, A, K = EPI_BIAS, EPI_STATS, EPI_ACCUM, EPI_MASK
     hot = {(PRO_BNRELU, B | S), (PRO_NONE, B | S), (PRO_BNBWD, K | S), (PRO_BNBWD, K | S | A), (PRO_BNBWD, K | A),
            (PRO_BNBWD, 0)}
+    if full and M == 128 and (pro, epi) in {(PRO_BNRELU, B | S), (PRO_NONE, B | S)}:
+        return "bgemm_kernel<4, %d, %d, true>" % (pro, epi)
     if full and M > 32 and (pro, epi) in hot:
         return "bgemm_kernel<2, %d, %d, true>" % (pro, epi)
     R = EPI_RELU
