@@ -970,18 +970,25 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const trunet_wgrad_a
     }
 }
 
+// XW columns per block, 256 / XW row groups: wide (64 x 4) for the big flat gradient image, narrow (16 x 16) for the small
+// per-layer tables (depthwise weight / bias partials: a few hundred columns x hundreds of rows, where 4 row groups meant ~130
+// dependent loads per thread, ~50 us per launch)
+template <int XW>
 __global__ __launch_bounds__(256) void reduce_partials_kernel(float* out, const float* __restrict__ partials, int nparts,
                                                               int numel, int accumulate) {
-    __shared__ double red[4][64];
-    const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + x;
+    constexpr int YG = 256 / XW;
+    __shared__ double red[YG][XW];
+    const int x = threadIdx.x % XW, y = threadIdx.x / XW;
+    const int i = blockIdx.x * XW + x;
     double s = 0.0;
     if (i < numel)
-        for (int g = y; g < nparts; g += 4) s += (double)partials[(size_t)g * numel + i];
+        for (int g = y; g < nparts; g += YG) s += (double)partials[(size_t)g * numel + i];
     red[y][x] = s;
     __syncthreads();
     if (y == 0 && i < numel) {
-        const double t = red[0][x] + red[1][x] + red[2][x] + red[3][x];
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < YG; ++k) t += red[k][x];
         out[i] = (accumulate ? out[i] : 0.f) + (float)t;
     }
 }
@@ -1052,7 +1059,11 @@ extern "C" int trunet_conv_wgrad(const trunet_wgrad_args* h, void* stream) {
 extern "C" int trunet_reduce_partials(float* out, const float* partials, int nparts, int numel, int accumulate,
                                       void* stream) {
     if (!out || !partials || nparts <= 0 || numel <= 0) return TRUNET_EINVAL;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((numel + 63) / 64), dim3(256), 0, (hipStream_t)stream, out,
-                       partials, nparts, numel, accumulate);
+    if (numel <= 4096 && nparts >= 64)
+        hipLaunchKernelGGL(reduce_partials_kernel<16>, dim3((numel + 15) / 16), dim3(256), 0, (hipStream_t)stream, out,
+                           partials, nparts, numel, accumulate);
+    else
+        hipLaunchKernelGGL(reduce_partials_kernel<64>, dim3((numel + 63) / 64), dim3(256), 0, (hipStream_t)stream, out,
+                           partials, nparts, numel, accumulate);
     return trunet_launch_status();
 }
