@@ -193,13 +193,18 @@ int trunet_launch_wgrad_small(const trunet_wgrad_args* h, hipStream_t st) {
 // =====================================================================================
 namespace {
 
+// RPB roles per block, LPR = 256 / RPB lanes per role (4 frames each).  16 x 16 is the original shape (one block covers
+// all 128 channels: 256 blocks for 256 partial images = 4 waves per CU, measured 2 ms slower than three separate launches);
+// 4 x 64 gives 4 blocks per partial image -- they write disjoint columns of it -- and 1 KiB row pieces per role.
+template <int RPB>
 __global__ __launch_bounds__(256) void pw_bwd_small_kernel(const trunet_pwbwd_args A, const int ngc_max, const int nroles) {
+    constexpr int LPR = 256 / RPB;
     const trunet_wgrad_args& a = A.w;
-    __shared__ float Ws[16][64];             // per role: W[m][c0 + j]
+    __shared__ float Ws[RPB][64];            // per role: W[m][c0 + j]
     const int tid = threadIdx.x;
-    const int l16 = tid & 15;
-    const int rl = tid >> 4;                 // role slot inside the block
-    const int role = blockIdx.x * 16 + rl;
+    const int l16 = tid % LPR;               // lane inside the role
+    const int rl = tid / LPR;                // role slot inside the block
+    const int role = blockIdx.x * RPB + rl;
     const bool has_role = role < nroles;
     const int cg = has_role ? role % ngc_max : 0, s = has_role ? role / ngc_max : 0;
     const trunet_seg& sg = a.seg[s];
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(256) void pw_bwd_small_kernel(const trunet_pwbwd_ar
     const bool act_role = has_role && c0 < sg.nchan;
     const bool bias_role = (role == 0);
     const int fl = dg.flags;
-    for (int idx = l16; idx < 64; idx += 16) {
+    for (int idx = l16; idx < 64; idx += LPR) {
         const int m = idx >> 3, j = idx & 7;
         Ws[rl][idx] = (act_role && m < a.M) ? A.W[(size_t)(m + a.w_m_off) * a.ldw_m + (size_t)(c0 + j) * a.ldw_c + sg.woff] : 0.f;
     }
@@ -221,14 +226,14 @@ __global__ __launch_bounds__(256) void pw_bwd_small_kernel(const trunet_pwbwd_ar
         for (int j = 0; j < 8; ++j) accW[i][j] = 0.f;
     }
     const bool on = sg.mode == TRUNET_PRO_BNRELU;
-    const int nch = a.NP / 64;
+    const int nch = a.NP / (4 * LPR);
     const int items = a.P * nch;
     const size_t dstr = (size_t)a.a_L * a.NP;
     const size_t sstr = (size_t)sg.L * a.NP;
     for (int it = blockIdx.y; it < items; it += gridDim.y) {
         const int pi = it / nch;
         const int p = a.p_begin + pi;
-        const int n = (it - pi * nch) * 64 + 4 * l16;
+        const int n = (it - pi * nch) * (4 * LPR) + 4 * l16;
         const int q = p + sg.pos_off;
         const bool valid = act_role && q >= 0 && q < sg.L;
         if (!valid && !bias_role) continue;
@@ -293,8 +298,9 @@ __global__ __launch_bounds__(256) void pw_bwd_small_kernel(const trunet_pwbwd_ar
         }
     }
     // ---- reduce over the 16 lanes of the role, then this role's entries of the partial image
-    auto sum16 = [](float v) {
-        v += __shfl_xor(v, 8, 16); v += __shfl_xor(v, 4, 16); v += __shfl_xor(v, 2, 16); v += __shfl_xor(v, 1, 16);
+    auto sum16 = [](float v) {                      // over the LPR lanes of the role
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, LPR);
         return v;
     };
     float* img = a.w_partials + (size_t)blockIdx.y * a.w_numel;
@@ -332,6 +338,9 @@ int trunet_launch_pw_bwd_small(const trunet_pwbwd_args* H, hipStream_t st) {
     if (h->NP % 64) return TRUNET_EINVAL;
     const int ngc = maxc / 8;
     const int nroles = h->nseg * ngc;
-    hipLaunchKernelGGL(pw_bwd_small_kernel, dim3((nroles + 15) / 16, WS_GRID), dim3(256), 0, st, *H, ngc, nroles);
+    if (h->NP % 256 == 0)
+        hipLaunchKernelGGL(pw_bwd_small_kernel<4>, dim3((nroles + 3) / 4, WS_GRID), dim3(256), 0, st, *H, ngc, nroles);
+    else
+        hipLaunchKernelGGL(pw_bwd_small_kernel<16>, dim3((nroles + 15) / 16, WS_GRID), dim3(256), 0, st, *H, ngc, nroles);
     return trunet_launch_status();
 }

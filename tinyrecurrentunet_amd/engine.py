@@ -900,9 +900,9 @@ class TRUNetEngine:
             if q1 < x1.L:
                 dy_x1[:, q1:].zero_()
         outs = [dict(out=dy_x1, src=x1_mask)] + ([dict(out=g_skip)] if skip is not None else [])
-        # decoder.5's 8-row layer stays on the three separate launches (1.64 ms): trunet_pw_bwd's vector-ALU variant
-        # for <= 8 rows is correct but measured slower at this size (2.7-3.3 ms: 256 partial images = 256 blocks
-        # leave too few waves in flight); TRUNET_FUSED_THIN=1 selects it
+        # decoder.5's 8-row layer stays on the three separate launches (1.56 ms): trunet_pw_bwd's vector-ALU variant for
+        # <= 8 rows is correct but slower at this size (2.5 ms with 4 blocks per partial image, 3.6 ms with one; same-box
+        # A/B); TRUNET_FUSED_THIN=1 selects it
         fused = FUSED_PWBWD and (pw.out_channels % 32 == 0 or (pw.out_channels <= 8 and FUSED_THIN))
         self._pw_bwd(w, N=N, NP=NP, P=Lp, M=pw.out_channels, dz=dy_pw, dz1=a_pw.t, dz_bn=a_pw.bn, W=pw.weight,
                      bias=pw.bias, segs=srcs, outs=outs, grads=grads, fused=fused)
