@@ -336,6 +336,9 @@ __global__ __launch_bounds__(256) void stft_loss_fwd_kernel(const float* __restr
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
     cpx* sa = (cpx*)smraw;
     cpx* sb = sa + n;
+    cpx* stw = sb + n;                       // the n/2 twiddles, staged once per block (three table reads per butterfly
+                                             // from global memory were most of a stage's latency)
+    for (int i = threadIdx.x; i < n / 2; i += 256) stw[i] = tw[i];
     __shared__ double red[12];
     const int f = blockIdx.x, b = blockIdx.y;
     const float* xb = x + (size_t)b * L;
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(256) void stft_loss_fwd_kernel(const float* __restr
         const float w = win[i];
         sa[i] = make_float2(w * xb[j], w * yb[j]);
     }
-    const cpx* Z = fft_lds(sa, sb, n, logn, tw, false);
+    const cpx* Z = fft_lds(sa, sb, n, logn, stw, false);
     float s1 = 0.f, s2 = 0.f, s3 = 0.f;
     for (int k = threadIdx.x; k <= n / 2; k += 256) {
         cpx X, Y;
@@ -377,6 +380,8 @@ __global__ __launch_bounds__(256) void stft_mag_kernel(const float* __restrict__
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
     cpx* sa = (cpx*)smraw;
     cpx* sb = sa + n;
+    cpx* stw = sb + n;
+    for (int i = threadIdx.x; i < n / 2; i += 256) stw[i] = tw[i];
     const int f = blockIdx.x, b = blockIdx.y;
     const float* xb = x + (size_t)b * L;
     const float* yb = y + (size_t)b * L;
@@ -385,7 +390,7 @@ __global__ __launch_bounds__(256) void stft_mag_kernel(const float* __restrict__
         const float w = win[i];
         sa[i] = make_float2(w * xb[j], w * yb[j]);
     }
-    const cpx* Z = fft_lds(sa, sb, n, logn, tw, false);
+    const cpx* Z = fft_lds(sa, sb, n, logn, stw, false);
     const size_t base = ((size_t)b * nframes + f) * (n / 2 + 1);
     for (int k = threadIdx.x; k <= n / 2; k += 256) {
         cpx X, Y;
@@ -432,6 +437,8 @@ __global__ __launch_bounds__(256) void stft_loss_bwd_kernel(const float* __restr
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
     cpx* sa = (cpx*)smraw;
     cpx* sb = sa + n;
+    cpx* stw = sb + n;
+    for (int i = threadIdx.x; i < n / 2; i += 256) stw[i] = tw[i];
     const int f = blockIdx.x, b = blockIdx.y;
     const float* xb = x + (size_t)b * L;
     const float* yb = y + (size_t)b * L;
@@ -440,7 +447,7 @@ __global__ __launch_bounds__(256) void stft_loss_bwd_kernel(const float* __restr
         const float w = win[i];
         sa[i] = make_float2(w * xb[j], w * yb[j]);
     }
-    cpx* Z = fft_lds(sa, sb, n, logn, tw, false);
+    cpx* Z = fft_lds(sa, sb, n, logn, stw, false);
     cpx* other = (Z == sa) ? sb : sa;
     const float c_sc = coef[0], c_mag = coef[1];
     // build the half spectrum of gradients in `other` (upper half zero), then inverse FFT, real part
@@ -461,7 +468,7 @@ __global__ __launch_bounds__(256) void stft_loss_bwd_kernel(const float* __restr
         }
         other[k] = G;
     }
-    const cpx* g = fft_lds(other, Z, n, logn, tw, true);
+    const cpx* g = fft_lds(other, Z, n, logn, stw, true);
     if (fr) {
         // windowed time-domain gradient of this frame, the window's support only: summed per sample by ola_gather_kernel
         float* fo = fr + ((size_t)b * gridDim.x + f) * wl;
@@ -571,7 +578,7 @@ extern "C" int trunet_stft_loss_fwd(const float* x, const float* y, const float*
     const int logn = ilog2(n);
     if (!x || !y || !win || !tw || !partials || B <= 0 || logn < 3 || n > 4096 || hop <= 0 || L <= n / 2) return TRUNET_EINVAL;
     const int nframes = 1 + L / hop;
-    hipLaunchKernelGGL(stft_loss_fwd_kernel, dim3(nframes, B), dim3(256), 2 * n * sizeof(cpx), ST, x, y, win, (const cpx*)tw,
+    hipLaunchKernelGGL(stft_loss_fwd_kernel, dim3(nframes, B), dim3(256), (2 * n + n / 2) * sizeof(cpx), ST, x, y, win, (const cpx*)tw,
                        partials, L, n, logn, hop, nframes);
     return trunet_launch_status();
 }
@@ -581,7 +588,7 @@ extern "C" int trunet_stft_mag(const float* x, const float* y, const float* win,
     const int logn = ilog2(n);
     if (!x || !win || !tw || !xmag || B <= 0 || logn < 3 || n > 4096 || hop <= 0 || L <= n / 2) return TRUNET_EINVAL;
     const int nframes = 1 + L / hop;
-    hipLaunchKernelGGL(stft_mag_kernel, dim3(nframes, B), dim3(256), 2 * n * sizeof(cpx), ST, x, y ? y : x, win,
+    hipLaunchKernelGGL(stft_mag_kernel, dim3(nframes, B), dim3(256), (2 * n + n / 2) * sizeof(cpx), ST, x, y ? y : x, win,
                        (const cpx*)tw, xmag, y ? ymag : nullptr, L, n, logn, hop, nframes);
     return trunet_launch_status();
 }
@@ -591,7 +598,7 @@ extern "C" int trunet_stft_loss_bwd(const float* x, const float* y, const float*
     const int logn = ilog2(n);
     if (!x || !y || !win || !tw || !coef || !gx || B <= 0 || logn < 3 || n > 4096 || hop <= 0 || L <= n / 2) return TRUNET_EINVAL;
     const int nframes = 1 + L / hop;
-    hipLaunchKernelGGL(stft_loss_bwd_kernel, dim3(nframes, B), dim3(256), 2 * n * sizeof(cpx), ST, x, y, win, (const cpx*)tw,
+    hipLaunchKernelGGL(stft_loss_bwd_kernel, dim3(nframes, B), dim3(256), (2 * n + n / 2) * sizeof(cpx), ST, x, y, win, (const cpx*)tw,
                        coef, gx, L, n, logn, hop, (float*)nullptr, 0, 0);
     return trunet_launch_status();
 }
@@ -605,7 +612,7 @@ extern "C" int trunet_stft_loss_bwd_gather(const float* x, const float* y, const
         return TRUNET_EINVAL;
     const int nframes = 1 + L / hop;
     const int left = (n - win_length) / 2;
-    hipLaunchKernelGGL(stft_loss_bwd_kernel, dim3(nframes, B), dim3(256), 2 * n * sizeof(cpx), ST, x, y, win, (const cpx*)tw,
+    hipLaunchKernelGGL(stft_loss_bwd_kernel, dim3(nframes, B), dim3(256), (2 * n + n / 2) * sizeof(cpx), ST, x, y, win, (const cpx*)tw,
                        coef, gx, L, n, logn, hop, frames, win_length, left);
     hipLaunchKernelGGL(ola_gather_kernel, dim3((L + 255) / 256, B), dim3(256), 0, ST, frames, gx, L, n, hop, nframes,
                        win_length, left);
