@@ -94,7 +94,11 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
             }
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e], 0.f);
+#ifdef TRUNET_THIN_NT
+        __builtin_nontemporal_store(acc, (f32x4*)(y + ((size_t)co * Lout + lo) * NP + n));
+#else
         *(f32x4*)(y + ((size_t)co * Lout + lo) * NP + n) = acc;
+#endif
     }
 }
 

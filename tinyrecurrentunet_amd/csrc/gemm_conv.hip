@@ -394,7 +394,11 @@ __global__ __launch_bounds__(256) void conv_smallm_kernel(const trunet_gemm_args
                 const size_t cstr = (size_t)sg.L * a.NP;
 #pragma unroll 4
                 for (int ci = 0; ci < sg.nchan; ++ci) {
+#ifdef TRUNET_THIN_NT
+                    f32x4 v = __builtin_nontemporal_load((const f32x4*)(src + ci * cstr));
+#else
                     f32x4 v = *(const f32x4*)(src + ci * cstr);
+#endif
                     const f32x4 k = Cl[cb + ci];
                     const f32x4 w0 = Wl[2 * (cb + ci)], w1 = Wl[2 * (cb + ci) + 1];
 #pragma unroll

@@ -90,7 +90,11 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const trunet_wgrad_arg
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
             const size_t o = (size_t)min(i, a.M - 1 - min(m0, a.M - 1)) * dstr;
+#ifdef TRUNET_THIN_NT
+            dz[i] = __builtin_nontemporal_load((const f32x4*)(pdz + o));
+#else
             dz[i] = *(const f32x4*)(pdz + o);
+#endif
             if (two) {
                 const f32x4 zz = *(const f32x4*)(pz1 + o);
 #pragma unroll
