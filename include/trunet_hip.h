@@ -382,6 +382,15 @@ int trunet_bf16_gemm(const trunet_bgemm_args* h_args, void* stream);
  * wfrag[((rt*nks_total + ks)*64 + lane)*8 + j] = A(32 rt + lane%32, 16 ks + 8 (lane/32) + j); returns nks_total (> 0) */
 int trunet_bf16_pack_weight(const float* W, void* wfrag, int M, int ldw_m, int ldw_c, int w_m_off, int nseg,
                             const int32_t* h_seg_nchan, const int32_t* h_seg_woff, void* stream);
+/* the same for a whole table of images in one launch: d_descs is a DEVICE array of n descriptors (ks0[s] = first k-step of segment s,
+ * nks_total as trunet_bf16_pack_weight returns it), max_elems = max over the table of ceil(M/32) * nks_total * 64 */
+typedef struct {
+    const float* W; void* out;
+    int32_t M, ldw_m, ldw_c, w_m_off, nseg, nks_total;
+    int32_t nchan[TRUNET_MAX_SEG], woff[TRUNET_MAX_SEG], ks0[TRUNET_MAX_SEG];
+    int32_t _pad;
+} trunet_bpack_desc;
+int trunet_bf16_pack_weights_batch(const trunet_bpack_desc* d_descs, int n, int max_elems, void* stream);
 /* weight gradient of the same implicit GEMM from octet tensors: dW[(m+w_m_off)*ldw_m + c*ldw_c + woff_s] = sum_{p,n<N}
  * dz[m][p + a_pos_off][n] pro_s(src_s[c][q_s(p)][n]), dz = a0 (PRO_NONE) or ac0 a0 + ac1 a1 + ac2; fp32 partial images / bias
  * partial rows exactly as trunet_conv_wgrad (trunet_conv_wgrad_nparts() images, image stride w_numel).  M <= 128, at most 40
@@ -444,6 +453,10 @@ int trunet_bf16_dwconv_bwd(const void* dy, const void* z, const float* ca, const
 /* layout changes: frames-last fp32 [C][L][NP] <-> octet bf16 (network input / output and the fp32 bottleneck of the bf16
  * path: FGRU); channels C..8*ceil(C/8)-1 of the octet tensor are written as zeros */
 int trunet_bf16_from_frames_last(const float* x, void* y_oct, int C, int L, int NP, void* stream);
+/* (N, C, L) fp32 of the module API <-> one octet [L][NP][8] directly (C <= 8: network input, output, output cotangent); frames
+ * N..NP-1 and channels C..7 of the octet tensor are written as zeros */
+int trunet_bf16_from_ncl(const float* x_ncl, void* y_oct, int N, int C, int L, int NP, void* stream);
+int trunet_bf16_to_ncl(const void* y_oct, float* x_ncl, int N, int C, int L, int NP, void* stream);
 int trunet_bf16_to_frames_last(const void* x_oct, float* y, int C, int L, int NP, void* stream);
 
 /* calibration: sustained fp32 MFMA rate at the device's operating clock (out: blocks*256 floats) */

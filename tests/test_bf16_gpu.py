@@ -415,6 +415,17 @@ def test_bf16_layout_round_trip():
         back = torch.empty_like(x)
         check(lib.trunet_bf16_to_frames_last(ptr16(y16), ptr(back), Cn, 5, 256, st), "to")
         assert torch.equal(back, _rb(x))
+    # the module API layout (N, C, L) <-> one octet, directly
+    for Cn, N, Ln, NP in ((4, 200, 257, 256), (8, 300, 70, 512), (3, 1, 33, 256)):
+        xn = rnd(N, Cn, Ln)
+        y16 = torch.full((1, Ln, NP, 8), float("nan"), device=DEV, dtype=torch.bfloat16)
+        check(lib.trunet_bf16_from_ncl(ptr(xn), ptr16(y16), N, Cn, Ln, NP, st), "from_ncl")
+        ref = torch.zeros(Cn, Ln, NP, device=DEV)
+        ref[:, :, :N] = xn.permute(1, 2, 0)
+        assert torch.equal(y16, to_oct(ref))
+        back = torch.full((N, Cn, Ln), float("nan"), device=DEV)
+        check(lib.trunet_bf16_to_ncl(ptr16(y16), ptr(back), N, Cn, Ln, NP, st), "to_ncl")
+        assert torch.equal(back, _rb(xn))
 
 
 def _pair(cin, seed=0):

@@ -85,6 +85,11 @@ class BWgradArgs(C.Structure):
                [("seg", BSeg * MAX_SEG)]
 
 
+class BPackDesc(C.Structure):
+    _fields_ = [("W", _fp), ("out", _fp)] + [(n, C.c_int32) for n in ("M", "ldw_m", "ldw_c", "w_m_off", "nseg", "nks_total")] + \
+               [("nchan", C.c_int32 * MAX_SEG), ("woff", C.c_int32 * MAX_SEG), ("ks0", C.c_int32 * MAX_SEG), ("_pad", C.c_int32)]
+
+
 class BDgradArgs(C.Structure):
     _fields_ = [("wfragT", _fp), ("out", _fp * MAX_SEG), ("mean", _fp * MAX_SEG), ("partials", _fp * MAX_SEG),
                 ("flags", C.c_int32 * MAX_SEG), ("nrt_total", C.c_int32)]
@@ -177,6 +182,7 @@ def _declare(L):
         "trunet_bf16_gemm_nparts": [],
         "trunet_bf16_gemm": [C.POINTER(BGemmArgs), p],
         "trunet_bf16_pack_weight": [p, p, i, i, i, i, i, C.POINTER(C.c_int32), C.POINTER(C.c_int32), p],
+        "trunet_bf16_pack_weights_batch": [p, i, i, p],
         "trunet_bf16_wgrad": [C.POINTER(BWgradArgs), p],
         "trunet_bf16_pw_bwd_nparts": [],
         "trunet_bf16_pw_bwd": [C.POINTER(BPwBwdArgs), p],
@@ -186,6 +192,8 @@ def _declare(L):
         "trunet_bf16_dwconv_fwd": [p, p, p, p, p, p, p, i, i, i, i, i, i, i, p],
         "trunet_bf16_dwconv_bwd": [p] * 14 + [i] * 7 + [p],
         "trunet_bf16_from_frames_last": [p, p, i, i, i, p],
+        "trunet_bf16_from_ncl": [p, p, i, i, i, i, p],
+        "trunet_bf16_to_ncl": [p, p, i, i, i, i, p],
         "trunet_bf16_to_frames_last": [p, p, i, i, i, p],
         "trunet_debug_mfma_peak": [p, i, i, p],
     }

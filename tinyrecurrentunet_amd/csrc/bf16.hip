@@ -301,6 +301,27 @@ __global__ void pack_weight_kernel(const float* __restrict__ W, u32x4* __restric
     out[i] = bf_pack8(f);
 }
 
+// every packed image of a step in ONE launch (blockIdx.y = descriptor): the ~40 per-GEMM pack launches of a training step were
+// 0.28 ms of 7-microsecond kernels
+__global__ void pack_weights_batch_kernel(const trunet_bpack_desc* __restrict__ descs) {
+    const trunet_bpack_desc& d = descs[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;           // (rt, ks, lane)
+    const int nrt = (d.M + 31) >> 5;
+    if (i >= nrt * d.nks_total * 64) return;
+    const int lane = i & 63, ks = (i >> 6) % d.nks_total, rt = (i >> 6) / d.nks_total;
+    const int m = rt * 32 + (lane & 31);
+    int s = 0;
+    for (int t = 1; t < d.nseg; ++t) if (ks >= d.ks0[t]) s = t;
+    const int cbase = (ks - d.ks0[s]) * 16 + 8 * (lane >> 5);
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ch = cbase + j;
+        f[j] = (m < d.M && ch < d.nchan[s]) ? d.W[(size_t)(m + d.w_m_off) * d.ldw_m + (size_t)ch * d.ldw_c + d.woff[s]] : 0.f;
+    }
+    ((u32x4*)d.out)[i] = bf_pack8(f);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Weight gradient.  The MFMA K axis is the frame axis, so both operands need 8 consecutive FRAMES of one channel per lane
 // while the octet layout delivers 8 CHANNELS of one frame.  A step is (position p, 64 frames): wave w loads the octets
@@ -939,9 +960,65 @@ __global__ void to_fl_kernel(const u32x4* __restrict__ x, float* __restrict__ y,
     }
 }
 
+// (N, C, L) fp32 of the module API <-> ONE octet [L][NP][8] (C <= 8: the network input, its output and the output's cotangent):
+// one pass through a 32 x 32 (frame, position) LDS tile per channel instead of a frames-last fp32 intermediate
+__global__ __launch_bounds__(256) void from_ncl_kernel(const float* __restrict__ x, u32x4* __restrict__ y, int N, int C, int L,
+                                                       int NP) {
+    __shared__ float t[8][32][33];
+    const int n0 = blockIdx.x * 32, l0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int cc = 0; cc < 8; ++cc)
+        for (int i = ty; i < 32; i += 8) {
+            const int n = n0 + i, l = l0 + tx;
+            t[cc][i][tx] = (cc < C && n < N && l < L) ? x[((size_t)n * C + cc) * L + l] : 0.f;
+        }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int l = l0 + i, n = n0 + tx;
+        if (l < L && n < NP) {
+            float f[8];
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) f[cc] = t[cc][tx][i];
+            y[(size_t)l * NP + n] = bf_pack8(f);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void to_ncl_kernel(const u32x4* __restrict__ y, float* __restrict__ x, int N, int C, int L,
+                                                     int NP) {
+    __shared__ float t[8][32][33];
+    const int n0 = blockIdx.x * 32, l0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int l = l0 + i, n = n0 + tx;
+        float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (l < L && n < NP) bf_unpack8(y[(size_t)l * NP + n], f);
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) t[cc][tx][i] = f[cc];
+    }
+    __syncthreads();
+    for (int cc = 0; cc < C; ++cc)
+        for (int i = ty; i < 32; i += 8) {
+            const int n = n0 + i, l = l0 + tx;
+            if (n < N && l < L) x[((size_t)n * C + cc) * L + l] = t[cc][i][tx];
+        }
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
+
+extern "C" int trunet_bf16_from_ncl(const float* x, void* y, int N, int C, int L, int NP, void* stream) {
+    if (!x || !y || N <= 0 || NP < N || L <= 0) return TRUNET_EINVAL;
+    if (C <= 0 || C > 8) return TRUNET_ENOTSUP;
+    hipLaunchKernelGGL(from_ncl_kernel, dim3((NP + 31) / 32, (L + 31) / 32), dim3(256), 0, ST, x, (u32x4*)y, N, C, L, NP);
+    return trunet_launch_status();
+}
+extern "C" int trunet_bf16_to_ncl(const void* y, float* x, int N, int C, int L, int NP, void* stream) {
+    if (!x || !y || N <= 0 || NP < N || L <= 0) return TRUNET_EINVAL;
+    if (C <= 0 || C > 8) return TRUNET_ENOTSUP;
+    hipLaunchKernelGGL(to_ncl_kernel, dim3((NP + 31) / 32, (L + 31) / 32), dim3(256), 0, ST, (const u32x4*)y, x, N, C, L, NP);
+    return trunet_launch_status();
+}
 
 extern "C" int trunet_bf16_gemm_nparts(void) { return BG_GRID * 4; }
 
@@ -1047,6 +1124,12 @@ extern "C" int trunet_bf16_pack_weight(const float* W, void* wfrag, int M, int l
                        w_m_off, d);
     const int rc = trunet_launch_status();
     return rc == TRUNET_OK ? ks : rc;
+}
+
+extern "C" int trunet_bf16_pack_weights_batch(const trunet_bpack_desc* d_descs, int n, int max_elems, void* stream) {
+    if (!d_descs || n <= 0 || max_elems <= 0) return TRUNET_EINVAL;
+    hipLaunchKernelGGL(pack_weights_batch_kernel, dim3((max_elems + 255) / 256, n), dim3(256), 0, ST, d_descs);
+    return trunet_launch_status();
 }
 
 extern "C" int trunet_bf16_wgrad(const trunet_bwgrad_args* h, void* stream) {

@@ -19,7 +19,7 @@ from . import engine as E
 import os
 
 from ._lib import (DG_ACCUM, DG_MASK, DG_STATS, DG_STORE, EPI_ACCUM, EPI_BIAS, EPI_MASK, EPI_RELU, EPI_STATS, PRO_BNBWD,
-                   PRO_BNRELU, PRO_NONE, BConvtArgs, BGemmArgs, BPwBwdArgs, BSeg, BWgradArgs, check, ptr, ptr16)
+                   PRO_BNRELU, PRO_NONE, BConvtArgs, BGemmArgs, BPackDesc, BPwBwdArgs, BSeg, BWgradArgs, check, ptr, ptr16)
 from .engine import BN_MOM, F_BINS, FRAME_PAD, Act, TRUNetEngine, _Timed, _seg_positions, ceil_to
 
 BF16 = torch.bfloat16
@@ -31,6 +31,10 @@ FUSED_PWBWD16 = os.environ.get("TRUNET_BF16_FUSED_PWBWD", "1") != "0"
 # Backward of the 64 -> 64 transposed convs (decoder.0-4): one fused launch (trunet_bf16_convt_bwd) instead of trunet_bf16_wgrad
 # + trunet_bf16_gemm over the tap segments; TRUNET_BF16_FUSED_CONVT=0 keeps the separate launches.
 FUSED_CONVT16 = os.environ.get("TRUNET_BF16_FUSED_CONVT", "1") != "0"
+# Every packed weight image of a step in one launch at the start of the forward (the plan is learnt during the first
+# step); TRUNET_BF16_BATCH_PACK=0 packs in front of each GEMM instead.
+BATCH_PACK16 = os.environ.get("TRUNET_BF16_BATCH_PACK", "1") != "0"
+PACK_POOL_ELEMS = 4 << 20          # bf16 elements of the persistent image pool (a step uses ~1.5 M)
 
 
 def bseg(src0, nchan, Ln, pos_mul=1, pos_off=0, pos_div=1, woff=0, mode=PRO_NONE, src1=None, c0=None, c1=None, c2=None):
@@ -91,6 +95,72 @@ def _bgemm_name(M, segs, epi):
 class TRUNetEngineBF16(TRUNetEngine):
     """TRUNetEngine with bf16 activation storage (see the module docstring)."""
 
+    # ------------------------------------------------------------------ packed weight images
+    def _pack(self, W, M, ldw_m, ldw_c, w_m_off, nchan, woff):
+        """Device address of the MFMA A-fragment image of (W, addressing): taken from this step's batch when the plan
+        knows it, else packed now (and added to the plan)."""
+        lib, st = L.lib(), L.stream()
+        nks = sum(_ksteps(c) for c in nchan)
+        key = (W.data_ptr(), M, ldw_m, ldw_c, w_m_off, tuple(nchan), tuple(woff))
+        plan = self.__dict__.setdefault("_pk", {})
+        if self.__dict__.get("_pkbuf") is None or self._pkbuf.device != W.device:
+            self._pkbuf = torch.empty(PACK_POOL_ELEMS, device=W.device, dtype=BF16)
+            self._pkoff, self._pkepoch, self._pkdirty = 0, 0, True
+            plan.clear()
+        e = plan.get(key)
+        if e is not None:
+            e["used"] = self._pkepoch
+            if e["epoch"] == self._pkepoch:
+                return e["ptr"]
+        else:
+            n = ((M + 31) // 32) * nks * 64 * 8
+            if self._pkoff + n > PACK_POOL_ELEMS:        # pool exhausted (many shapes): start over, everything repacks
+                plan.clear()
+                self._pkoff = 0
+            e = dict(ptr=self._pkbuf.data_ptr() + 2 * self._pkoff, W=W.data_ptr(), M=M, ldw_m=ldw_m, ldw_c=ldw_c,
+                     w_m_off=w_m_off, nchan=list(nchan), woff=list(woff), nks=nks, epoch=-1, used=self._pkepoch, elems=n)
+            self._pkoff += (n + 63) // 64 * 64
+            plan[key] = e
+            self._pkdirty = True
+        ns = len(nchan)
+        rc = lib.trunet_bf16_pack_weight(W.data_ptr(), e["ptr"], M, ldw_m, ldw_c, w_m_off, ns, (C.c_int32 * ns)(*nchan),
+                                         (C.c_int32 * ns)(*woff), st)
+        if rc != nks:
+            raise L.TrunetHipError("trunet_bf16_pack_weight: code %d (expected %d k-steps)" % (rc, nks))
+        e["epoch"] = self._pkepoch
+        return e["ptr"]
+
+    def _pack_all(self):
+        """Start of a forward: a new epoch; pack every image the plan holds in one launch."""
+        if self.__dict__.get("_pkbuf") is None:
+            return
+        self._pkepoch += 1
+        plan = self._pk
+        stale = [k for k, e in plan.items() if e["used"] < self._pkepoch - 2]      # shapes / storages no longer in use
+        for k in stale:
+            del plan[k]
+            self._pkdirty = True
+        if not BATCH_PACK16 or not plan:
+            return
+        if self._pkdirty:
+            arr = (BPackDesc * len(plan))()
+            for d, e in zip(arr, plan.values()):
+                d.W, d.out = e["W"], e["ptr"]
+                d.M, d.ldw_m, d.ldw_c, d.w_m_off, d.nseg, d.nks_total = e["M"], e["ldw_m"], e["ldw_c"], e["w_m_off"], \
+                    len(e["nchan"]), e["nks"]
+                k0 = 0
+                for i, (cn, wo) in enumerate(zip(e["nchan"], e["woff"])):
+                    d.nchan[i], d.woff[i], d.ks0[i] = cn, wo, k0
+                    k0 += _ksteps(cn)
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            self._pkdesc = host.to(self._pkbuf.device)
+            self._pkmax = max(e["elems"] // 8 for e in plan.values())
+            self._pkdirty = False
+        check(L.lib().trunet_bf16_pack_weights_batch(self._pkdesc.data_ptr(), len(plan), self._pkmax, L.stream()),
+              "bf16_pack_weights_batch")
+        for e in plan.values():
+            e["epoch"] = self._pkepoch
+
     # ------------------------------------------------------------------ launches
     def _get16(self, w, name, Cn, Ln, NP):
         return w.get(name, (_oct(Cn), Ln, NP, 8), dtype=BF16)
@@ -104,10 +174,7 @@ class TRUNetEngineBF16(TRUNetEngine):
         nchan = (C.c_int32 * nseg)(*[s.nchan for s in segs])
         woff = (C.c_int32 * nseg)(*[s.woff for s in segs])
         nks = sum(_ksteps(s.nchan) for s in segs)
-        wfrag = w.flat("wfrag", ((M + 31) // 32) * nks * 64 * 8, dtype=BF16)
-        rc = lib.trunet_bf16_pack_weight(ptr(W), ptr16(wfrag), M, ldw_m, ldw_c, w_m_off, nseg, nchan, woff, st)
-        if rc != nks:
-            raise L.TrunetHipError("trunet_bf16_pack_weight: code %d (expected %d k-steps)" % (rc, nks))
+        wfrag_ptr = self._pack(W, M, ldw_m, ldw_c, w_m_off, [s.nchan for s in segs], [s.woff for s in segs])
         a = BGemmArgs()
         a.NP, a.N, a.P, a.p_begin = NP, N, P, p_begin
         a.M, a.out_L, a.out_pos_off, a.nseg, a.nks_total = M, out_L, out_pos_off, nseg, nks
@@ -116,7 +183,7 @@ class TRUNetEngineBF16(TRUNetEngine):
             s.kstep0 = k0
             k0 += _ksteps(s.nchan)
             a.seg[i] = s
-        a.out, a.wfrag = ptr16(out), ptr16(wfrag)
+        a.out, a.wfrag = ptr16(out), wfrag_ptr
         if bias is not None:
             epi |= EPI_BIAS
             a.bias = ptr(bias)
@@ -262,10 +329,11 @@ class TRUNetEngineBF16(TRUNetEngine):
             w.gen += 1
         lib, st = L.lib(), L.stream()
         acts = {}
+        self._pack_all()
 
-        xt = w.get("x", (Cin, F_BINS, NP))
-        check(lib.trunet_to_frames_last(ptr(x), ptr(xt), N, Cin, F_BINS, NP, st), "to_frames_last")
-        x16 = Act16(self._to16(w, "x16", xt, Cin, F_BINS, NP), Cin, F_BINS)
+        x16t = self._get16(w, "x16", Cin, F_BINS, NP)
+        check(lib.trunet_bf16_from_ncl(ptr(x), ptr16(x16t), N, Cin, F_BINS, NP, st), "bf16_from_ncl")
+        x16 = Act16(x16t, Cin, F_BINS)
         acts["x"] = x16
         # first conv (network.py:13): one segment per tap of the strided input, bias + ReLU in the epilogue
         c0 = net.encoder[0].StandardConv1d[0]
@@ -299,9 +367,8 @@ class TRUNetEngineBF16(TRUNetEngine):
             cur = acts["dec%d.pw" % i] = self._pw(w, "dec%d.pw" % i, [cur, skip], seq[0], seq[1], N, NP, training,
                                                   x1_left=left)
             cur = acts["dec%d" % i] = self._convT(w, "dec%d" % i, cur, seq[3], seq[4] if i < 5 else None, N, NP, training)
-        o32 = self._to32(w, "out.f32", cur.t, cur.C, cur.L, NP)
         out = torch.empty((N, cur.C, cur.L), device=x.device, dtype=torch.float32)
-        check(lib.trunet_from_frames_last(ptr(o32), ptr(out), N, cur.C, cur.L, NP, st), "from_frames_last")
+        check(lib.trunet_bf16_to_ncl(ptr16(cur.t), ptr(out), N, cur.C, cur.L, NP, st), "bf16_to_ncl")
         return out, (acts, N, NP, w, w.gen)
 
     # ------------------------------------------------------------------ backward pieces
@@ -350,16 +417,22 @@ class TRUNetEngineBF16(TRUNetEngine):
             return False
         nks = _ksteps(M)
         nrt_total = sum(s.nchan // 32 for s in segs)
-        wfragT = w.flat("wfragT", nrt_total * nks * 64 * 8, dtype=BF16)
-        one = (C.c_int32 * 1)(M)
-        zero = (C.c_int32 * 1)(0)
-        rt0 = 0
-        for s in segs:       # W^T of this source: A(c, m) = W[m*K + woff + c]
-            rc = lib.trunet_bf16_pack_weight(ptr(W.data), wfragT.data_ptr() + rt0 * nks * 64 * 16, s.nchan, 1, K, s.woff, 1,
-                                             one, zero, st)
-            if rc != nks:
-                raise L.TrunetHipError("trunet_bf16_pack_weight (W^T): code %d" % rc)
-            rt0 += s.nchan // 32
+        # W^T of all sources as ONE image: A(c, m) = W[m*K + c] for c over the concatenated source channels (the sources'
+        # woff are consecutive: woff_s = channels before s), i.e. row tiles of the sources one after the other
+        assert [s.woff for s in segs] == [sum(t.nchan for t in segs[:i]) for i in range(len(segs))]
+        wfragT_ptr = self._pack(W.data, K, 1, K, 0, [M], [0]) if K <= 128 else None
+        if wfragT_ptr is None:       # more than 128 rows: two images back to back are not one pool entry: pack per source
+            wfragT = w.flat("wfragT", nrt_total * nks * 64 * 8, dtype=BF16)
+            one = (C.c_int32 * 1)(M)
+            zero = (C.c_int32 * 1)(0)
+            rt0 = 0
+            for s in segs:
+                rc = lib.trunet_bf16_pack_weight(ptr(W.data), wfragT.data_ptr() + rt0 * nks * 64 * 16, s.nchan, 1, K, s.woff, 1,
+                                                 one, zero, st)
+                if rc != nks:
+                    raise L.TrunetHipError("trunet_bf16_pack_weight (W^T): code %d" % rc)
+                rt0 += s.nchan // 32
+            wfragT_ptr = wfragT.data_ptr()
         a = BPwBwdArgs()
         aw = a.w
         aw.NP, aw.N, aw.P, aw.p_begin = NP, N, P, 0
@@ -370,7 +443,7 @@ class TRUNetEngineBF16(TRUNetEngine):
         aw.w_numel = self._wg_total
         aw.w_partials, aw.b_partials = self._wg_slot(W), self._wg_slot(bias)
         aw.b_stride, aw.b_off = self._wg_total, 0
-        a.dg.wfragT, a.dg.nrt_total = ptr16(wfragT), nrt_total
+        a.dg.wfragT, a.dg.nrt_total = wfragT_ptr, nrt_total
         nparts = lib.trunet_bf16_pw_bwd_nparts()
         stat_parts = []
         for i, (sg, o) in enumerate(zip(segs, outs)):
@@ -413,13 +486,7 @@ class TRUNetEngineBF16(TRUNetEngine):
         Ci, Co = ct.in_channels, ct.out_channels
         if Ci != 64 or Co != 64 or (k, s_) not in ((3, 1), (5, 2), (3, 2)) or pad != s_ // 2:
             return False
-        nks = 4 * k
-        wfragT = w.flat("wfragT", 2 * nks * 64 * 8, dtype=BF16)
-        nch = (C.c_int32 * k)(*([Co] * k))
-        wof = (C.c_int32 * k)(*range(k))
-        rc = lib.trunet_bf16_pack_weight(ptr(ct.weight.data), ptr16(wfragT), Ci, Co * k, k, 0, k, nch, wof, st)
-        if rc != nks:
-            raise L.TrunetHipError("trunet_bf16_pack_weight (convT W^T): code %d" % rc)
+        wfragT_ptr = self._pack(ct.weight.data, Ci, Co * k, k, 0, [Co] * k, list(range(k)))
         a = BConvtArgs()
         a.NP, a.N, a.Lin, a.Lout, a.K, a.S, a.pad, a.Ci, a.Co = NP, N, a_pw.L, Lo, k, s_, pad, Ci, Co
         a.dy, a.z = ptr16(dy), ptr16(z)
@@ -427,7 +494,7 @@ class TRUNetEngineBF16(TRUNetEngine):
         a.src, a.s_scale, a.s_shift, a.s_mean = ptr16(a_pw.t), ptr(a_pw.bn.scale), ptr(a_pw.bn.shift), ptr(a_pw.bn.mean)
         nparts = lib.trunet_bf16_convt_bwd_nparts()
         part = w.flat("ct16_partials", nparts * Ci * 2)
-        a.wfragT, a.dsrc, a.partials = ptr16(wfragT), ptr16(dy_pw), ptr(part)
+        a.wfragT, a.dsrc, a.partials = wfragT_ptr, ptr16(dy_pw), ptr(part)
         a.w_numel = self._wg_total
         a.w_partials, a.b_partials = self._wg_slot(ct.weight), self._wg_slot(ct.bias)
         a.b_stride, a.b_off = self._wg_total, 0
@@ -508,9 +575,8 @@ class TRUNetEngineBF16(TRUNetEngine):
         self._wg_begin(w)
         gout = gout.contiguous()
         last = acts["dec5"]
-        g32 = w.get("dy:dec5.f32", (last.C, last.L, NP))
-        check(lib.trunet_to_frames_last(ptr(gout), ptr(g32), N, last.C, last.L, NP, st), "to_frames_last")
-        dyt = self._to16(w, "dy:dec5", g32, last.C, last.L, NP)
+        dyt = self._get16(w, "dy:dec5", last.C, last.L, NP)
+        check(lib.trunet_bf16_from_ncl(ptr(gout), ptr16(dyt), N, last.C, last.L, NP, st), "bf16_from_ncl")
         up = (dyt, last.t, None)
         for i in range(5, -1, -1):
             seq = (net.decoder[i].LastTrCNN if i == 5 else net.decoder[i].TrCNN) if i > 0 else net.decoder[0].FirstTrCNN
