@@ -61,7 +61,9 @@ enum { TRUNET_EPI_BIAS = 1,   /* add bias[m]                                    
        TRUNET_EPI_STATS = 2,  /* accumulate per-channel statistics into `partials`                 */
        TRUNET_EPI_ACCUM = 4,  /* add the value already stored at the output location               */
        TRUNET_EPI_MASK = 8,   /* multiply by [e0[m]*zmask + e1[m] > 0] (ReLU backward)              */
-       TRUNET_EPI_RELU = 16   /* max(.,0) before the store                                          */ };
+       TRUNET_EPI_RELU = 16,  /* max(.,0) before the store                                          */
+       TRUNET_EPI_F32OUT = 32 /* trunet_bf16_gemm only: `out` is an fp32 frames-last tensor [rows][out_L][NP] (the GRU input
+                                 projection, whose consumer is the fp32 recurrence); with BIAS only               */ };
 
 /* Implicit-GEMM conv (forward of Conv1d k=1 / ConvTranspose1d, and their data gradients):
  *   out[m][p+out_pos_off][n] = epi( sum_seg sum_c A_seg(m,c) * pro_seg(src_seg[c][q_seg(p)][n]) )
@@ -370,7 +372,8 @@ typedef struct {
  * gradients).  wfrag: the weight as packed by trunet_bf16_pack_weight ([row tile][k-step][64 lanes][8 bf16], MFMA A-fragment
  * order).  M <= 128.  Statistics partial rows: partials[trunet_bf16_gemm_nparts()][M_stat][2] (zero-filled by the call). */
 typedef struct {
-    int32_t NP, N, P, p_begin, M, out_L, out_pos_off, nseg, epi, M_stat, nks_total, _pad;
+    int32_t NP, N, P, p_begin, M, out_L, out_pos_off, nseg, epi, M_stat, nks_total;
+    int32_t m_out_off;        /* TRUNET_EPI_F32OUT: first output row of this launch in `out` (and in `bias`) */
     void* out; const void* wfrag; const float* bias; const void* zmask;
     const float* e0; const float* e1; const float* e2; float* partials;
     trunet_bseg seg[TRUNET_MAX_SEG];

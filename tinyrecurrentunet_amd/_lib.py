@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("TRUNET_HIP_LIB") or os.path.join(_HERE, "csrc", "libt
 MAX_SEG = 5
 TRUNET_OK, TRUNET_EINVAL, TRUNET_ELAUNCH, TRUNET_ENOTSUP = 0, -1, -2, -3
 PRO_NONE, PRO_BNRELU, PRO_BNBWD = 0, 1, 2
-EPI_BIAS, EPI_STATS, EPI_ACCUM, EPI_MASK, EPI_RELU = 1, 2, 4, 8, 16
+EPI_BIAS, EPI_STATS, EPI_ACCUM, EPI_MASK, EPI_RELU, EPI_F32OUT = 1, 2, 4, 8, 16, 32
 
 _fp = C.c_void_p
 
@@ -73,7 +73,7 @@ class BSeg(C.Structure):
 
 class BGemmArgs(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("NP", "N", "P", "p_begin", "M", "out_L", "out_pos_off", "nseg", "epi", "M_stat",
-                                         "nks_total", "_pad")] + \
+                                         "nks_total", "m_out_off")] + \
                [(n, _fp) for n in ("out", "wfrag", "bias", "zmask", "e0", "e1", "e2", "partials")] + \
                [("seg", BSeg * MAX_SEG)]
 

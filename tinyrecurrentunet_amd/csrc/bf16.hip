@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(const trunet_bgemm_args a
     for (int i = tid; i < a.nks_total * 2 * 3 * 8; i += 256) Cf[i] = 0.f;
     for (int i = tid; i < 128; i += 256) {
         const bool ok = i < a.M;
-        Ep[i] = (ok && has(TRUNET_EPI_BIAS)) ? a.bias[i] : 0.f;
+        Ep[i] = (ok && has(TRUNET_EPI_BIAS)) ? a.bias[i + (has(TRUNET_EPI_F32OUT) ? a.m_out_off : 0)] : 0.f;
         Ep[128 + i] = (ok && has(TRUNET_EPI_MASK)) ? a.e0[i] : 0.f;
         Ep[256 + i] = (ok && has(TRUNET_EPI_MASK)) ? a.e1[i] : 0.f;
         Ep[384 + i] = (ok && has(TRUNET_EPI_MASK) && a.e2) ? a.e2[i] : 0.f;
@@ -238,6 +238,13 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(const trunet_bgemm_args a
                     if (!FULL) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) if (m0 + i >= a.M) val[i] = 0.f;   // padded channels of the last octet
+                    }
+                    if (has(TRUNET_EPI_F32OUT)) {      // fp32 frames-last rows (GRU input projection): 128 B per row and half-wave
+                        float* o32 = (float*)a.out + ((size_t)(a.m_out_off + m0) * a.out_L + p + a.out_pos_off) * a.NP + nn;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (FULL || m0 + i < a.M) o32[(size_t)i * a.out_L * a.NP] = val[i];
+                        continue;
                     }
                     u32x2 o;
                     o[0] = bf_pack(val[0], val[1]);
@@ -1039,6 +1046,7 @@ extern "C" int trunet_bf16_gemm(const trunet_bgemm_args* h, void* stream) {
     if ((h->epi & TRUNET_EPI_STATS) && (!h->partials || h->M_stat < h->M)) return TRUNET_EINVAL;
     if ((h->epi & TRUNET_EPI_MASK) && (!h->zmask || !h->e0 || !h->e1)) return TRUNET_EINVAL;
     if ((h->epi & TRUNET_EPI_BIAS) && !h->bias) return TRUNET_EINVAL;
+    if ((h->epi & TRUNET_EPI_F32OUT) && ((h->epi & ~(TRUNET_EPI_F32OUT | TRUNET_EPI_BIAS)) || h->m_out_off < 0)) return TRUNET_EINVAL;
     for (int s = 0; s < h->nseg; ++s) {
         const trunet_bseg& sg = h->seg[s];
         if (!bseg_ok(sg) || sg.kstep0 < 0) return TRUNET_EINVAL;
@@ -1077,6 +1085,9 @@ extern "C" int trunet_bf16_gemm(const trunet_bgemm_args* h, void* stream) {
         if (pro == TRUNET_PRO_NONE && h->epi == (B | S) && nrt_all == 4) BG_LAUNCH(4, TRUNET_PRO_NONE, B | S, true);
         if (pro == TRUNET_PRO_BNRELU && h->epi == (B | S)) BG_LAUNCH(2, TRUNET_PRO_BNRELU, B | S, true);
         if (pro == TRUNET_PRO_NONE && h->epi == (B | S)) BG_LAUNCH(2, TRUNET_PRO_NONE, B | S, true);
+        if (pro == TRUNET_PRO_BNRELU && h->epi == (B | TRUNET_EPI_F32OUT) && nrt_all == 4)
+            BG_LAUNCH(4, TRUNET_PRO_BNRELU, B | TRUNET_EPI_F32OUT, true);
+        if (pro == TRUNET_PRO_NONE && h->epi == (K | S)) BG_LAUNCH(2, TRUNET_PRO_NONE, K | S, true);
         if (pro == TRUNET_PRO_BNBWD && h->epi == (K | S)) BG_LAUNCH(2, TRUNET_PRO_BNBWD, K | S, true);
         if (pro == TRUNET_PRO_BNBWD && h->epi == (K | S | A)) BG_LAUNCH(2, TRUNET_PRO_BNBWD, K | S | A, true);
         if (pro == TRUNET_PRO_BNBWD && h->epi == (K | A)) BG_LAUNCH(2, TRUNET_PRO_BNBWD, K | A, true);

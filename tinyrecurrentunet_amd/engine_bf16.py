@@ -18,7 +18,7 @@ from . import _lib as L
 from . import engine as E
 import os
 
-from ._lib import (DG_ACCUM, DG_MASK, DG_STATS, DG_STORE, EPI_ACCUM, EPI_BIAS, EPI_MASK, EPI_RELU, EPI_STATS, PRO_BNBWD,
+from ._lib import (DG_ACCUM, DG_MASK, DG_STATS, DG_STORE, EPI_ACCUM, EPI_BIAS, EPI_F32OUT, EPI_MASK, EPI_RELU, EPI_STATS, PRO_BNBWD,
                    PRO_BNRELU, PRO_NONE, BConvtArgs, BGemmArgs, BPackDesc, BPwBwdArgs, BSeg, BWgradArgs, check, ptr, ptr16)
 from .engine import BN_MOM, F_BINS, FRAME_PAD, Act, TRUNetEngine, _Timed, _seg_positions, ceil_to
 
@@ -31,6 +31,9 @@ FUSED_PWBWD16 = os.environ.get("TRUNET_BF16_FUSED_PWBWD", "1") != "0"
 # Backward of the 64 -> 64 transposed convs (decoder.0-4): one fused launch (trunet_bf16_convt_bwd) instead of trunet_bf16_wgrad
 # + trunet_bf16_gemm over the tap segments; TRUNET_BF16_FUSED_CONVT=0 keeps the separate launches.
 FUSED_CONVT16 = os.environ.get("TRUNET_BF16_FUSED_CONVT", "1") != "0"
+# The FGRU input projection (M = 384), its data gradient and its weight gradients on the bf16 kernels (the recurrence, its
+# W_hh gradients and the block's pointwise conv stay fp32); TRUNET_BF16_GRU_PROJ=0 keeps the whole block on the fp32 kernels.
+GRU_PROJ16 = os.environ.get("TRUNET_BF16_GRU_PROJ", "1") != "0"
 # Every packed weight image of a step in one launch at the start of the forward (the plan is learnt during the first
 # step); TRUNET_BF16_BATCH_PACK=0 packs in front of each GEMM instead.
 BATCH_PACK16 = os.environ.get("TRUNET_BF16_BATCH_PACK", "1") != "0"
@@ -79,8 +82,8 @@ def _bgemm_name(M, segs, epi):
     full = M % 32 == 0 and all(s.nchan % 16 == 0 for s in segs)
     B, S, A, K = EPI_BIAS, EPI_STATS, EPI_ACCUM, EPI_MASK
     hot = {(PRO_BNRELU, B | S), (PRO_NONE, B | S), (PRO_BNBWD, K | S), (PRO_BNBWD, K | S | A), (PRO_BNBWD, K | A),
-           (PRO_BNBWD, 0)}
-    if full and M == 128 and (pro, epi) in {(PRO_BNRELU, B | S), (PRO_NONE, B | S)}:
+           (PRO_BNBWD, 0), (PRO_NONE, K | S)}
+    if full and M == 128 and (pro, epi) in {(PRO_BNRELU, B | S), (PRO_NONE, B | S), (PRO_BNRELU, B | EPI_F32OUT)}:
         return "bgemm_kernel<4, %d, %d, true>" % (pro, epi)
     if full and M > 32 and (pro, epi) in hot:
         return "bgemm_kernel<2, %d, %d, true>" % (pro, epi)
@@ -166,7 +169,7 @@ class TRUNetEngineBF16(TRUNetEngine):
         return w.get(name, (_oct(Cn), Ln, NP, 8), dtype=BF16)
 
     def _gemm16(self, w, *, N, NP, P, M, out, out_L, W, ldw_m, ldw_c, segs, p_begin=0, out_pos_off=0, w_m_off=0, epi=0,
-                bias=None, zmask=None, e0=None, e1=None, e2=None, stats=None):
+                bias=None, zmask=None, e0=None, e1=None, e2=None, stats=None, m_out_off=0):
         """trunet_bf16_gemm: out[m][p + out_pos_off] = epi(sum_seg W_seg . pro(src_seg)); the fp32 weight is packed into
         MFMA A fragments first (trunet_bf16_pack_weight, a few microseconds)."""
         lib, st = L.lib(), L.stream()
@@ -183,7 +186,8 @@ class TRUNetEngineBF16(TRUNetEngine):
             s.kstep0 = k0
             k0 += _ksteps(s.nchan)
             a.seg[i] = s
-        a.out, a.wfrag = ptr16(out), wfrag_ptr
+        a.out, a.wfrag = (ptr(out) if epi & EPI_F32OUT else ptr16(out)), wfrag_ptr
+        a.m_out_off = m_out_off
         if bias is not None:
             epi |= EPI_BIAS
             a.bias = ptr(bias)
@@ -299,6 +303,65 @@ class TRUNetEngineBF16(TRUNetEngine):
                   "bn_eval_affine")
         return Act16(out, Cn, Lo, st)
 
+    def _gru16(self, w, cur, gru, N, NP, training):
+        """engine._gru with the input projection (both directions, 6H = 384 rows) on the bf16 GEMM: three launches of 128
+        rows that write fp32 frames-last gi for the fp32 recurrence kernel"""
+        lib = L.lib()
+        Hh = gru.hidden_size
+        wih = w.get("wih", (6 * Hh, gru.input_size))
+        bih = w.get("bih", (6 * Hh,))
+        torch.cat((gru.weight_ih_l0.data, gru.weight_ih_l0_reverse.data), 0, out=wih)
+        torch.cat((gru.bias_ih_l0.data, gru.bias_ih_l0_reverse.data), 0, out=bih)
+        Lg = cur.L
+        gi = w.get("gi", (6 * Hh, Lg, NP))
+        for m0 in range(0, 6 * Hh, 128):
+            self._gemm16(w, N=N, NP=NP, P=Lg, M=min(128, 6 * Hh - m0), out=gi, out_L=Lg, W=wih, ldw_m=gru.input_size, ldw_c=1,
+                         segs=[cur.seg()], bias=bih, epi=EPI_F32OUT, w_m_off=m0, m_out_off=m0)
+        hout = w.get("hout", (2 * Hh, Lg, NP))
+        gates = w.get("gates", (2, 4, Hh, Lg, NP)) if training else None
+        check(lib.trunet_gru_fwd(ptr(gi), ptr(gru.weight_hh_l0.data), ptr(gru.bias_hh_l0.data),
+                                 ptr(gru.weight_hh_l0_reverse.data), ptr(gru.bias_hh_l0_reverse.data), ptr(hout),
+                                 ptr(gates), Hh, Lg, NP, L.stream()), "gru_fwd")
+        return Act(hout, 2 * Hh, Lg)
+
+    def _bwd_fgru16(self, w, N, NP, blk, up, hout, src16, dy_src16, grads):
+        """engine._bwd_fgru with the input projection's data gradient and weight gradients on the bf16 kernels: dgi is
+        converted to octets once and feeds the W_ih gradients (trunet_bf16_wgrad, sources = enc5's activation) and
+        dy(enc5) = W_ih^T dgi with ReLU mask and BatchNorm-backward sums (trunet_bf16_gemm, 24 k-steps)."""
+        lib, st = L.lib(), L.stream()
+        dy, z, bn = up
+        conv, gru = blk.conv[0], blk.GRU
+        Hh, Lg = gru.hidden_size, hout.L
+        dhout = w.get("dhout", (2 * Hh, Lg, NP))
+        self._pw_bwd(w, N=N, NP=NP, P=Lg, M=conv.out_channels, dz=dy, dz1=z, dz_bn=bn, W=conv.weight, bias=conv.bias,
+                     segs=[hout.seg()], outs=[dict(out=dhout)], grads=grads, fused=E.FUSED_PWBWD)
+        dgi = w.get("dgi", (6 * Hh, Lg, NP))
+        dghn = w.get("dghn", (2 * Hh, Lg, NP))
+        gates = w.t["gates"]
+        check(lib.trunet_gru_bwd(ptr(dhout), ptr(hout.t), ptr(gates), ptr(gru.weight_hh_l0.data),
+                                 ptr(gru.weight_hh_l0_reverse.data), ptr(dgi), ptr(dghn), Hh, Lg, NP, N, st), "gru_bwd")
+        dgi16 = self._to16(w, "dgi16", dgi, 6 * Hh, Lg, NP)
+        for d, sfx in enumerate(("", "_reverse")):
+            whh = getattr(gru, "weight_hh_l0" + sfx)
+            bhh = getattr(gru, "bias_hh_l0" + sfx)
+            wih_p = getattr(gru, "weight_ih_l0" + sfx)
+            bih_p = getattr(gru, "bias_ih_l0" + sfx)
+            hseg = E.make_seg(hout.t[d * Hh:(d + 1) * Hh], Hh, Lg, pos_off=(1 if d else -1))
+            self._wgrad(w, N=N, NP=NP, P=Lg, M=2 * Hh, dz=dgi, dz_L=Lg, dz_bn=None, a_m_off=d * 3 * Hh, W=whh,
+                        ldw_m=Hh, ldw_c=1, segs=[hseg], grads=grads, bias=bhh, b_off=0)
+            self._wgrad(w, N=N, NP=NP, P=Lg, M=Hh, dz=dghn, dz_L=Lg, dz_bn=None, a_m_off=d * Hh, w_m_off=2 * Hh,
+                        W=whh, ldw_m=Hh, ldw_c=1, segs=[hseg], grads=grads, bias=bhh, b_off=2 * Hh)
+            # input projection weights: rows [0, 128) and [128, 192) of this direction's 3H = 192 rows of dgi
+            for r0, M in ((0, 128), (128, 3 * Hh - 128)):
+                oct0 = (d * 3 * Hh + r0) // 8
+                self._wgrad16(w, N=N, NP=NP, P=Lg, M=M, dz=dgi16[oct0:], dz_L=Lg, dz_bn=None, W=wih_p,
+                              ldw_m=gru.input_size, ldw_c=1, segs=[src16.seg()], grads=grads, bias=bih_p, w_m_off=r0, b_off=r0)
+        wih = w.t["wih"]
+        nparts = self._gemm16(w, N=N, NP=NP, P=Lg, M=src16.C, out=dy_src16, out_L=src16.L, W=wih, ldw_m=1,
+                              ldw_c=gru.input_size, segs=[bseg(dgi16, 6 * Hh, Lg)], zmask=src16.t, e0=src16.bn.scale,
+                              e1=src16.bn.shift, e2=src16.bn.mean, stats=src16.C)
+        self._bn_bwd(w, src16.bn, nparts, grads)
+
     def _to16(self, w, name, t32, Cn, Ln, NP):
         t16 = self._get16(w, name, Cn, Ln, NP)
         check(L.lib().trunet_bf16_from_frames_last(ptr(t32), ptr16(t16), Cn, Ln, NP, L.stream()), "bf16_from_frames_last")
@@ -350,9 +413,12 @@ class TRUNetEngineBF16(TRUNetEngine):
             cur = acts["enc%d.pw" % i] = self._pw(w, "enc%d.pw" % i, [cur], seq[0], seq[1], N, NP, training)
             cur = acts["enc%d" % i] = self._dw(w, "enc%d" % i, cur, seq[3], seq[4], N, NP, training)
 
-        # FGRU in fp32 between two layout conversions
-        enc5f = acts["enc5.f32"] = Act(self._to32(w, "z:enc5.f32", cur.t, cur.C, cur.L, NP), cur.C, cur.L, cur.bn)
-        acts["hout"] = self._gru(w, enc5f, net.FGRU.GRU, N, NP, training)
+        # FGRU: the recurrence and the block's pointwise conv in fp32
+        if GRU_PROJ16:
+            acts["hout"] = self._gru16(w, cur, net.FGRU.GRU, N, NP, training)
+        else:
+            enc5f = acts["enc5.f32"] = Act(self._to32(w, "z:enc5.f32", cur.t, cur.C, cur.L, NP), cur.C, cur.L, cur.bn)
+            acts["hout"] = self._gru(w, enc5f, net.FGRU.GRU, N, NP, training)
         fg = acts["fgru.f32"] = TRUNetEngine._pw(self, w, "fgru", [acts["hout"]], net.FGRU.conv[0], net.FGRU.conv[1], N, NP,
                                                  training)
         cur = acts["fgru"] = Act16(self._to16(w, "z:fgru16", fg.t, fg.C, fg.L, NP), fg.C, fg.L, fg.bn)
@@ -594,11 +660,16 @@ class TRUNetEngineBF16(TRUNetEngine):
             up = (dy_x1, x1.t, x1.bn)
 
         # -------- FGRU (fp32)
-        fg, enc5f, enc5 = acts["fgru.f32"], acts["enc5.f32"], acts["enc5"]
+        fg, enc5 = acts["fgru.f32"], acts["enc5"]
         dyf = self._to32(w, "dy:fgru.f32", up[0], fg.C, fg.L, NP)
-        dy5f = w.get("dy:enc5.f32", (enc5f.C, enc5f.L, NP))
-        self._bwd_fgru(w, N, NP, net.FGRU, (dyf, fg.t, fg.bn), acts["hout"], enc5f, enc5f, dy5f, grads)
-        dy5 = self._to16(w, "dy:enc5", dy5f, enc5.C, enc5.L, NP)
+        if "enc5.f32" in acts:
+            enc5f = acts["enc5.f32"]
+            dy5f = w.get("dy:enc5.f32", (enc5f.C, enc5f.L, NP))
+            self._bwd_fgru(w, N, NP, net.FGRU, (dyf, fg.t, fg.bn), acts["hout"], enc5f, enc5f, dy5f, grads)
+            dy5 = self._to16(w, "dy:enc5", dy5f, enc5.C, enc5.L, NP)
+        else:
+            dy5 = self._get16(w, "dy:enc5", enc5.C, enc5.L, NP)
+            self._bwd_fgru16(w, N, NP, net.FGRU, (dyf, fg.t, fg.bn), acts["hout"], enc5, dy5, grads)
         up = (dy5, enc5.t, enc5.bn)
 
         for i in range(5, 0, -1):
