@@ -470,9 +470,8 @@ def test_bf16_backward_matches_fp32_backward_on_the_same_forward_state():
             acts32[k] = Act(t, a.C, a.L, a.bn)
         else:
             acts32[k] = a
-    acts32["fgru"] = acts["fgru.f32"]            # the block's fp32 conv output (enc5 is the exact fp32 copy made above)
-    if "enc5.f32" in acts:
-        acts32["enc5"] = acts["enc5.f32"]
+    if "fgru.f32" in acts:                       # TRUNET_BF16_GRU_PROJ=0: the block ran in fp32 on fp32 copies
+        acts32["fgru"], acts32["enc5"] = acts["fgru.f32"], acts["enc5.f32"]
     e32 = TRUNetEngine(net)
     g32 = e32.backward((acts32, N, NP, w, gen), gout)
     worst = 0.0

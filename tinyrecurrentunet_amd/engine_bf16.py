@@ -5,8 +5,9 @@ Same layer schedule as ``engine.TRUNetEngine`` (``/root/reference/network.py:122
 ``trunet_bf16_*`` kernels: every activation between layers and every activation gradient is stored as bf16 in the
 octet layout ``[C/8][L][NP][8]`` and multiplied on ``v_mfma_f32_32x32x16_bf16``; accumulators, BatchNorm statistics and
 coefficients, weight gradients (the flat fp32 gradient tensor of the fp32 engine, so the all-reduce and FusedAdamW are
-unchanged) and the master weights stay fp32.  The frequency-recurrent bottleneck (FGRU: 16 positions, 1.5 % of the
-activation bytes) runs on the fp32 kernels between two layout conversions.
+unchanged) and the master weights stay fp32.  Of the frequency-recurrent bottleneck (FGRU) only the recurrence itself runs
+on the fp32 kernels (fp32 gi / gates / hidden states); its input projection, pointwise conv and all their gradients are
+bf16 GEMMs like the rest of the body.
 
 What is not offered in bf16: the TGRU block and the stand-alone block classes (fp32 only).
 """
@@ -324,7 +325,7 @@ class TRUNetEngineBF16(TRUNetEngine):
                                  ptr(gates), Hh, Lg, NP, L.stream()), "gru_fwd")
         return Act(hout, 2 * Hh, Lg)
 
-    def _bwd_fgru16(self, w, N, NP, blk, up, hout, src16, dy_src16, grads):
+    def _bwd_fgru16(self, w, N, NP, blk, up, hout, hout16, src16, dy_src16, grads):
         """engine._bwd_fgru with the input projection's data gradient and weight gradients on the bf16 kernels: dgi is
         converted to octets once and feeds the W_ih gradients (trunet_bf16_wgrad, sources = enc5's activation) and
         dy(enc5) = W_ih^T dgi with ReLU mask and BatchNorm-backward sums (trunet_bf16_gemm, 24 k-steps)."""
@@ -332,25 +333,31 @@ class TRUNetEngineBF16(TRUNetEngine):
         dy, z, bn = up
         conv, gru = blk.conv[0], blk.GRU
         Hh, Lg = gru.hidden_size, hout.L
-        dhout = w.get("dhout", (2 * Hh, Lg, NP))
-        self._pw_bwd(w, N=N, NP=NP, P=Lg, M=conv.out_channels, dz=dy, dz1=z, dz_bn=bn, W=conv.weight, bias=conv.bias,
-                     segs=[hout.seg()], outs=[dict(out=dhout)], grads=grads, fused=E.FUSED_PWBWD)
+        # the block's pointwise conv + BatchNorm (bf16, fused); its data gradient goes to the fp32 recurrence kernel as fp32
+        dhout16 = self._get16(w, "dhout16", 2 * Hh, Lg, NP)
+        self._pw_bwd16(w, N=N, NP=NP, P=Lg, M=conv.out_channels, dz=dy, dz1=z, dz_bn=bn, W=conv.weight, bias=conv.bias,
+                       segs=[hout16.seg()], outs=[dict(out=dhout16)], grads=grads)
+        dhout = self._to32(w, "dhout", dhout16, 2 * Hh, Lg, NP)
         dgi = w.get("dgi", (6 * Hh, Lg, NP))
         dghn = w.get("dghn", (2 * Hh, Lg, NP))
         gates = w.t["gates"]
         check(lib.trunet_gru_bwd(ptr(dhout), ptr(hout.t), ptr(gates), ptr(gru.weight_hh_l0.data),
                                  ptr(gru.weight_hh_l0_reverse.data), ptr(dgi), ptr(dghn), Hh, Lg, NP, N, st), "gru_bwd")
         dgi16 = self._to16(w, "dgi16", dgi, 6 * Hh, Lg, NP)
+        dghn16 = self._to16(w, "dghn16", dghn, 2 * Hh, Lg, NP)
         for d, sfx in enumerate(("", "_reverse")):
             whh = getattr(gru, "weight_hh_l0" + sfx)
             bhh = getattr(gru, "bias_hh_l0" + sfx)
             wih_p = getattr(gru, "weight_ih_l0" + sfx)
             bih_p = getattr(gru, "bias_ih_l0" + sfx)
-            hseg = E.make_seg(hout.t[d * Hh:(d + 1) * Hh], Hh, Lg, pos_off=(1 if d else -1))
-            self._wgrad(w, N=N, NP=NP, P=Lg, M=2 * Hh, dz=dgi, dz_L=Lg, dz_bn=None, a_m_off=d * 3 * Hh, W=whh,
-                        ldw_m=Hh, ldw_c=1, segs=[hseg], grads=grads, bias=bhh, b_off=0)
-            self._wgrad(w, N=N, NP=NP, P=Lg, M=Hh, dz=dghn, dz_L=Lg, dz_bn=None, a_m_off=d * Hh, w_m_off=2 * Hh,
-                        W=whh, ldw_m=Hh, ldw_c=1, segs=[hseg], grads=grads, bias=bhh, b_off=2 * Hh)
+            # recurrent weights: h_{t-1} of this direction (the neighbouring position) against the (r, z) rows of dgi and the
+            # n rows of dghn
+            hseg = bseg(hout16.t[d * Hh // 8:(d + 1) * Hh // 8], Hh, Lg, pos_off=(1 if d else -1))
+            self._wgrad16(w, N=N, NP=NP, P=Lg, M=2 * Hh, dz=dgi16[d * 3 * Hh // 8:], dz_L=Lg, dz_bn=None, W=whh, ldw_m=Hh,
+                          ldw_c=1, segs=[hseg], grads=grads, bias=bhh, b_off=0)
+            hseg = bseg(hout16.t[d * Hh // 8:(d + 1) * Hh // 8], Hh, Lg, pos_off=(1 if d else -1))
+            self._wgrad16(w, N=N, NP=NP, P=Lg, M=Hh, dz=dghn16[d * Hh // 8:], dz_L=Lg, dz_bn=None, W=whh, ldw_m=Hh,
+                          ldw_c=1, segs=[hseg], grads=grads, bias=bhh, w_m_off=2 * Hh, b_off=2 * Hh)
             # input projection weights: rows [0, 128) and [128, 192) of this direction's 3H = 192 rows of dgi
             for r0, M in ((0, 128), (128, 3 * Hh - 128)):
                 oct0 = (d * 3 * Hh + r0) // 8
@@ -415,13 +422,16 @@ class TRUNetEngineBF16(TRUNetEngine):
 
         # FGRU: the recurrence and the block's pointwise conv in fp32
         if GRU_PROJ16:
-            acts["hout"] = self._gru16(w, cur, net.FGRU.GRU, N, NP, training)
+            hout = acts["hout"] = self._gru16(w, cur, net.FGRU.GRU, N, NP, training)
+            # the block's pointwise conv on the bf16 kernels as well: the recurrence output once more as octets
+            h16 = acts["hout16"] = Act16(self._to16(w, "hout16", hout.t, hout.C, hout.L, NP), hout.C, hout.L)
+            cur = acts["fgru"] = self._pw(w, "fgru", [h16], net.FGRU.conv[0], net.FGRU.conv[1], N, NP, training)
         else:
             enc5f = acts["enc5.f32"] = Act(self._to32(w, "z:enc5.f32", cur.t, cur.C, cur.L, NP), cur.C, cur.L, cur.bn)
             acts["hout"] = self._gru(w, enc5f, net.FGRU.GRU, N, NP, training)
-        fg = acts["fgru.f32"] = TRUNetEngine._pw(self, w, "fgru", [acts["hout"]], net.FGRU.conv[0], net.FGRU.conv[1], N, NP,
-                                                 training)
-        cur = acts["fgru"] = Act16(self._to16(w, "z:fgru16", fg.t, fg.C, fg.L, NP), fg.C, fg.L, fg.bn)
+            fg = acts["fgru.f32"] = TRUNetEngine._pw(self, w, "fgru", [acts["hout"]], net.FGRU.conv[0], net.FGRU.conv[1], N,
+                                                     NP, training)
+            cur = acts["fgru"] = Act16(self._to16(w, "z:fgru16", fg.t, fg.C, fg.L, NP), fg.C, fg.L, fg.bn)
 
         seq = net.decoder[0].FirstTrCNN
         cur = acts["dec0.pw"] = self._pw(w, "dec0.pw", [cur], seq[0], seq[1], N, NP, training)
@@ -660,16 +670,16 @@ class TRUNetEngineBF16(TRUNetEngine):
             up = (dy_x1, x1.t, x1.bn)
 
         # -------- FGRU (fp32)
-        fg, enc5 = acts["fgru.f32"], acts["enc5"]
-        dyf = self._to32(w, "dy:fgru.f32", up[0], fg.C, fg.L, NP)
+        enc5 = acts["enc5"]
         if "enc5.f32" in acts:
-            enc5f = acts["enc5.f32"]
+            fg, enc5f = acts["fgru.f32"], acts["enc5.f32"]
+            dyf = self._to32(w, "dy:fgru.f32", up[0], fg.C, fg.L, NP)
             dy5f = w.get("dy:enc5.f32", (enc5f.C, enc5f.L, NP))
             self._bwd_fgru(w, N, NP, net.FGRU, (dyf, fg.t, fg.bn), acts["hout"], enc5f, enc5f, dy5f, grads)
             dy5 = self._to16(w, "dy:enc5", dy5f, enc5.C, enc5.L, NP)
         else:
             dy5 = self._get16(w, "dy:enc5", enc5.C, enc5.L, NP)
-            self._bwd_fgru16(w, N, NP, net.FGRU, (dyf, fg.t, fg.bn), acts["hout"], enc5, dy5, grads)
+            self._bwd_fgru16(w, N, NP, net.FGRU, up, acts["hout"], acts["hout16"], enc5, dy5, grads)
         up = (dy5, enc5.t, enc5.bn)
 
         for i in range(5, 0, -1):
