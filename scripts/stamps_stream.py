@@ -42,5 +42,10 @@ tot = s[14] - s[0]
 print("N=%d grid=%d: %.3f ms per launch; frame 0 of workgroup 0: %d cycles" % (N, grid, dt * 1e3, tot))
 for a, b in zip(order[:-1], order[1:]):
     print("  %-20s %8d  %5.1f %%" % (names[a], s[b] - s[a], 100.0 * (s[b] - s[a]) / tot))
+enc = [2, 3, 4, 5, 6, 10, 11, 12]
+print("  encoder.2..5, projection x3 (pointwise + depthwise + save each): " + " ".join(str(int(s[b] - s[a])) for a, b in zip(enc[:-1], enc[1:])))
+for i in range(1, 5):
+    a = 9 if i == 1 else 12 + 2 * i
+    print("  dec%d: pw %d  convT+restore %d" % (i, s[13 + 2 * i] - s[a], s[14 + 2 * i] - s[13 + 2 * i]))
 print("  enc3 (it=1, 2 column tiles = 128 MFMAs/wave): wait for own fragments %d  request next %d  pw %d  guards+dw+syncs %d" % (
     s[28] - s[27], s[29] - s[28], s[30] - s[29], s[31] - s[30]))

@@ -159,19 +159,23 @@ __device__ __forceinline__ void sf_pw(const float* af, float* lds, int src1, int
 
 // ConvTranspose1d(64 -> 64, k = TAPS, stride S_, padding S_/2) + folded BatchNorm + ReLU.  Output position p = S_ j + e:
 // class e uses the taps with (e + pad - tap) % S_ == 0 at source column j + (e + pad - tap) / S_ -- a dense GEMM per tap.
+// Only the positions [p0, p0 + Ln) that the next layer reads are produced (the crops of network.py:96-97 drop the rest:
+// with them every class is a whole number of 32-column tiles instead of one more tile for one or two columns).
 template <int TAPS, int S_, int NQN = 0>
 __device__ __forceinline__ void sf_convT(const float* af, float* lds, int src, int lsi, int dst, int lsd, int Lout,
-                                         float* fpn = nullptr, const float* tile_next = nullptr) {
+                                         int p0, int Ln, float* fpn = nullptr, const float* tile_next = nullptr) {
     const int tid_ = sf_tid();
     const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), h = lane >> 5, c = lane & 31;
     const int rt = wave & 1;
     constexpr int PAD = S_ / 2;
+    const int pend = min(Lout, p0 + Ln);
     int ucount = 0;
     bool pf = NQN > 0;
     const f32x4* pn = (const f32x4*)tile_next + lane;
 #pragma unroll
     for (int e = 0; e < S_; ++e) {
-        const int nj = (Lout - e + S_ - 1) / S_;
+        const int j0 = p0 > e ? (p0 - e + S_ - 1) / S_ : 0;
+        const int nj = (pend - e + S_ - 1) / S_ - j0;
         const int tiles = (nj + 31) >> 5;
         for (int jt = 0; jt < tiles; ++jt, ++ucount) {
             if ((ucount & 1) != (wave >> 1)) continue;
@@ -183,16 +187,16 @@ __device__ __forceinline__ void sf_convT(const float* af, float* lds, int src, i
                 constexpr int BIG = 8 * S_;
                 if ((e + PAD - tap + BIG) % S_ == 0) {
                     const int d = (e + PAD - tap + BIG) / S_ - 8;
-                    sf_mm<32, NQN>(acc, af + tap * 32, lds + src + h * lsi + 4 + jt * 32 + c + d, 2 * lsi, pf, fpn, pn);
+                    sf_mm<32, NQN>(acc, af + tap * 32, lds + src + h * lsi + 4 + j0 + jt * 32 + c + d, 2 * lsi, pf, fpn, pn);
                     pf = false;
                 }
             }
-            const int p = S_ * (jt * 32 + c) + e;
+            const int p = S_ * (j0 + jt * 32 + c) + e;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const float v = fmaxf(acc[r] + af[TAPS * 32 + r], 0.f);
-                if (p < Lout) lds[dst + row * lsd + 4 + p] = v;
+                if (p < pend) lds[dst + row * lsd + 4 + p] = v;
             }
         }
     }
@@ -456,6 +460,7 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
                 if (it == 1) SF_STAMP(31);
                 if (it < 3) sf_save(lds, SF_R0, LSA, it == 0 ? sk2 : (it == 1 ? sk3 : sk4), 128, it == 2 ? 3 : 4);
             }
+            SF_STAMP(it < 4 ? 3 + it : 6 + it);              // 3..6 encoder.2-5, 10..12 projection passes
         }
         SF_SYNC();
 #if defined(SF_ABL) && (SF_ABL & 4)      // diagnostic: encoder + projection only (does a smaller code footprint stay in the I-cache?)
@@ -542,7 +547,7 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
             sf_restore(lds, SF_R0, LSA, sk4, 128, 3);
             SF_TAKE(28);
             SF_REQUEST(28, A.o_dpw[1], wave & 1);                             // decoder.1 pw: 192 -> 64
-            sf_convT<3, 2>(fs, lds, SF_R1B, LSA, SF_R1A, LSA, 31);
+            sf_convT<3, 2>(fs, lds, SF_R1B, LSA, SF_R1A, LSA, 31, 0, 31);
             sf_guards(lds, SF_R1A, 64, LSA, 31);
             SF_SYNC();
         }
@@ -564,6 +569,7 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
             sf_pw<32, 64, 2>(fs, lds, SF_R1A, LSA, i == 1 ? 0 : 1, SF_R0, LSA, SF_R1B, LSA, P, 64, 0, true);
             sf_guards(lds, SF_R1B, 64, LSA, P);
             SF_SYNC();
+            SF_STAMP(13 + 2 * i);                             // 15, 17, 19, 21: pointwise conv of block i done
             // skip tensor of the next block: enc3 (L 64), enc2 (L 64), enc1 (L 128), enc0 (64 x 128): requested now,
             // written to R0 after the ConvT (R0's current content, this block's skip, was last read before the barrier)
             f32x4 rr[16];
@@ -574,11 +580,14 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
             // next pw: decoder.(i+1) 192 -> 64 (28 quads per tile), or decoder.5 128 -> 8 (one padded tile of 20 quads)
             sf_load<28>(fp, blob + A.o_dpw[i + 1] + (size_t)(i < 4 ? (wave & 1) : 0) * (28 * 256), lane);
             __builtin_amdgcn_sched_barrier(0);
-            if (i & 1) sf_convT<5, 2>(fs, lds, SF_R1B, LSA, SF_R1A, LSA, Lo);
-            else sf_convT<3, 1>(fs, lds, SF_R1B, LSA, SF_R1A, LSA, Lo);
+            // the consumer (next block / decoder.5) reads positions [1, 1 + Pn) of this output
+            const int Pn = i <= 2 ? 64 : 128;
+            if (i & 1) sf_convT<5, 2>(fs, lds, SF_R1B, LSA, SF_R1A, LSA, Lo, 1, Pn);
+            else sf_convT<3, 1>(fs, lds, SF_R1B, LSA, SF_R1A, LSA, Lo, 1, Pn);
             sf_restore_commit(rr, lds, SF_R0, LSA, skC, sklq);
             sf_guards(lds, SF_R1A, 64, LSA, Lo);
             SF_SYNC();
+            SF_STAMP(14 + 2 * i);                             // 16, 18, 20, 22: block i done
         }
         SF_STAMP(13);
         {   // ---------------- decoder.5 (LastTrCNN): pw 128 -> 8 (+BN+ReLU), ConvT 8 -> 8 k5 s2 -> 257, linear
