@@ -34,7 +34,7 @@ for _ in range(20):
     lib.trunet_stream_fwd(x.data_ptr(), y.data_ptr(), f.blob.data_ptr(), f._offs, 26, scratch.data_ptr(), N, 4, st)
 torch.cuda.synchronize()
 dt = (time.time() - t0) / 20
-s = scratch[grid * 45056:].view(torch.int64)[:32].cpu().numpy().astype(np.int64)
+s = scratch[grid * 45056:].view(torch.int64)[:64].cpu().numpy().astype(np.int64)
 names = {0: "x+first conv", 1: "enc1", 2: "enc2-5 + GRU proj", 7: "W_hh load", 23: "GRU recurrence", 26: "guards",
          8: "fgru pw + dec0", 9: "dec1-4", 13: "dec5"}
 order = [0, 1, 2, 7, 23, 26, 8, 9, 13, 14]
@@ -49,3 +49,6 @@ for i in range(1, 5):
     print("  dec%d: pw %d  convT+restore %d" % (i, s[13 + 2 * i] - s[a], s[14 + 2 * i] - s[13 + 2 * i]))
 print("  enc3 (it=1, 2 column tiles = 128 MFMAs/wave): wait for own fragments %d  request next %d  pw %d  guards+dw+syncs %d" % (
     s[28] - s[27], s[29] - s[28], s[30] - s[29], s[31] - s[30]))
+d = s[32:32 + 17]
+print("  dec4 pw (wave 0): entry->group0 %d; per group [mm1, mm2, stores, to next]: %s" % (
+    d[1] - d[0], " ".join("[%d %d %d]" % (d[2 + 4 * g] - d[1 + 4 * g], d[3 + 4 * g] - d[2 + 4 * g], d[4 + 4 * g] - d[3 + 4 * g]) for g in range(4))))

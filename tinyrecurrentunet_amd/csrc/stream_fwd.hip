@@ -64,6 +64,18 @@ __device__ __forceinline__ void sf_load(float* af, const float* tile, int lane) 
     }
 }
 
+// The B-operand reads of an MFMA stream must be bare `ds_read_b32 v, base offset:imm`: ONE vector-ALU instruction between
+// two MFMAs of a wave that is alone on its SIMD costs 12 cycles of matrix pipe, an address add feeding the read 24
+// (scripts/dbg/mfma_mix.hip: 64 -> 76 -> 88 cycles per 32x32x2 MFMA, 33 -> 45 -> 56 per 16x16x4; the read alone: +2).
+// hipcc folds a constant into the 16-bit offset field only if the whole constant fits, and the buffer offsets inside the
+// 160 KiB arena do not: the lane's base is made opaque (in the LDS address space) and the stream's own constants fit.
+typedef __attribute__((address_space(3))) const float* sf_lptr;
+__device__ __forceinline__ sf_lptr sf_lds_base(const float* p) {
+    sf_lptr q = (sf_lptr)p;
+    asm volatile("" : "+v"(q));
+    return q;
+}
+
 // acc += A(af[0..KP)) * B, B[k = 2 kk + h][j = c] = S[kk * rs2] (S is the lane's base: row h, column of this lane).
 // One wave per SIMD must hide the LDS latency of its own B operand: the read for k-pair kk + LA is issued right before
 // the MFMA of k-pair kk, and the order is pinned (hipcc otherwise sinks every ds_read directly in front of the MFMA that
@@ -76,6 +88,8 @@ __device__ __forceinline__ void sf_mm(f32x16& acc, const float* af, const float*
                                       float* fpn = nullptr, const f32x4* pn = nullptr) {
     constexpr int LA = 6;
     float b[KP];
+    const sf_lptr S0 = sf_lds_base(S), S1 = sf_lds_base(S + (KP > 32 ? 32 : 0) * rs2);      // 32 k-pairs x 1152 B per base
+#define SF_B(kk) ((kk) < 32 ? S0[(kk) * rs2] : S1[((kk) - 32) * rs2])
 #if defined(SF_ABL) && (SF_ABL & 1)      // diagnostic: no LDS reads for the B operand (wrong results, timing only)
 #pragma unroll
     for (int kk = 0; kk < KP; ++kk) b[kk] = af[kk] + (float)rs2;
@@ -84,14 +98,14 @@ __device__ __forceinline__ void sf_mm(f32x16& acc, const float* af, const float*
 #define SF_ABL_NOB 0
 #endif
 #pragma unroll
-    for (int kk = 0; kk < LA && kk < KP && !SF_ABL_NOB; ++kk) b[kk] = S[kk * rs2];
+    for (int kk = 0; kk < LA && kk < KP && !SF_ABL_NOB; ++kk) b[kk] = SF_B(kk);
 #if defined(SF_ABL) && (SF_ABL & 2)      // diagnostic: every unrolled MFMA block runs twice (second pass from the I-cache)
     for (int rep_ = 0; rep_ < 2; ++rep_) {
         asm volatile("" ::: "memory");
 #endif
 #pragma unroll
     for (int kk = 0; kk < KP; ++kk) {
-        if (kk + LA < KP && !SF_ABL_NOB) b[kk + LA] = S[(kk + LA) * rs2];
+        if (kk + LA < KP && !SF_ABL_NOB) b[kk + LA] = SF_B(kk + LA);
         if constexpr (NQN > 0) {
             if (pf) {
 #pragma unroll
@@ -108,6 +122,7 @@ __device__ __forceinline__ void sf_mm(f32x16& acc, const float* af, const float*
 #if defined(SF_ABL) && (SF_ABL & 2)
     }
 #endif
+#undef SF_B
 }
 
 // zero the guard columns [-4, 0) and [L, L + 4) of a [rows][ls] buffer
@@ -157,51 +172,119 @@ __device__ __forceinline__ void sf_pw(const float* af, float* lds, int src1, int
     }
 }
 
-// ConvTranspose1d(64 -> 64, k = TAPS, stride S_, padding S_/2) + folded BatchNorm + ReLU.  Output position p = S_ j + e:
-// class e uses the taps with (e + pad - tap) % S_ == 0 at source column j + (e + pad - tap) / S_ -- a dense GEMM per tap.
-// Only the positions [p0, p0 + Ln) that the next layer reads are produced (the crops of network.py:96-97 drop the rest:
-// with them every class is a whole number of 32-column tiles instead of one more tile for one or two columns).
-template <int TAPS, int S_, int NQN = 0>
-__device__ __forceinline__ void sf_convT(const float* af, float* lds, int src, int lsi, int dst, int lsd, int Lout,
-                                         int p0, int Ln, float* fpn = nullptr, const float* tile_next = nullptr) {
+// ---- 16-row tiles (v_mfma_f32_16x16x4_f32) for the 64-channel layers (FGRU.conv, every decoder layer): with 32-row tiles
+// two of the four waves hold the SAME row tile's fragments (every weight crosses the L1 twice) and layers with 16 or 32
+// positions leave waves or half of every tile idle.  Four 16-row tiles give each wave its own quarter of the weights
+// (half the fragment registers and half the fragment traffic), every wave works on every column, and a 16-position
+// layer is one exact tile.  Lane l holds A[row l & 15][k = 4 kq + (l >> 4)] and B[k = 4 kq + (l >> 4)][column l & 15];
+// accumulator register r of lane l is C[row 4 (l >> 4) + r][column l & 15].
+// acc[ct] += A(af[0..KQ)) * B for NCT column tiles of 16: S is the lane's base (row l >> 4, column l & 15), rs4 = 4 rows.
+template <int KQ, int NCT>
+__device__ __forceinline__ void sf_mm16(f32x4 (&acc)[NCT], const float* af, const float* S, int rs4) {
+#ifndef SF_LA16
+#define SF_LA16 8
+#endif
+    constexpr int LA = SF_LA16, NT = KQ * NCT;
+    float b[NT];
+    const sf_lptr S0 = sf_lds_base(S), S1 = sf_lds_base(S + (KQ > 24 ? 24 : 0) * rs4);      // 24 k-quads x 2304 B per base
+#define SF_B(x) ((x) / NCT < 24 ? S0[((x) / NCT) * rs4 + ((x) % NCT) * 16] : S1[((x) / NCT - 24) * rs4 + ((x) % NCT) * 16])
+#pragma unroll
+    for (int x = 0; x < LA && x < NT; ++x) b[x] = SF_B(x);
+#pragma unroll
+    for (int x = 0; x < NT; ++x) {
+        if (x + LA < NT) b[x + LA] = SF_B(x + LA);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[x % NCT] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[x / NCT], b[x], acc[x % NCT], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef SF_B
+}
+
+// Pointwise conv (+ folded BatchNorm) over one or two sources, M <= 64 rows as 16-row tiles.  SPLIT = false: wave = row
+// tile, every wave covers all P columns; SPLIT = true (M <= 16): one row tile, the waves split the column groups.
+// NCT column tiles of 16 per group (1 for the 16-position layers, else 2).
+template <int KQ1, int KQ2, int NCT, bool SPLIT>
+__device__ __forceinline__ void sf_pw16(const float* af, float* lds, int src1, int ls1, int coff1, int src2, int ls2, int dst,
+                                        int lsd, int P, int M, bool relu, long long* stamps = nullptr) {
     const int tid_ = sf_tid();
-    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), h = lane >> 5, c = lane & 31;
-    const int rt = wave & 1;
+    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), q = lane >> 4, j = lane & 15;
+    const int row = (SPLIT ? 0 : 16 * wave) + 4 * q;
+    int sidx = 0;
+#ifdef SF_STAMPS
+#define SF_ISTAMP() do { if (stamps && tid_ == 0) stamps[sidx++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SF_ISTAMP() do { (void)sidx; (void)stamps; } while (0)
+#endif
+    SF_ISTAMP();
+    const int ng = (P + 16 * NCT - 1) / (16 * NCT);
+    for (int g = SPLIT ? wave : 0; g < ng; g += SPLIT ? 4 : 1) {
+        f32x4 acc[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int c0 = g * 16 * NCT + j;
+        SF_ISTAMP();
+#if !defined(SF_NOMM) || SF_NOMM != 1
+        sf_mm16<KQ1, NCT>(acc, af, lds + src1 + q * ls1 + 4 + c0 + coff1, 4 * ls1);
+#endif
+        SF_ISTAMP();
+#if !defined(SF_NOMM) || SF_NOMM != 2
+        if constexpr (KQ2 > 0) sf_mm16<KQ2, NCT>(acc, af + KQ1, lds + src2 + q * ls2 + 4 + c0, 4 * ls2);
+#endif
+        SF_ISTAMP();
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const int col = c0 + 16 * ct;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[ct][r] + af[KQ1 + KQ2 + r];
+                if (relu) v = fmaxf(v, 0.f);
+                if (col < P && row + r < M) lds[dst + (row + r) * lsd + 4 + col] = v;
+            }
+        }
+        SF_ISTAMP();
+    }
+}
+
+// ConvTranspose1d(64 -> 64, k = TAPS, stride S_, padding S_/2) + folded BatchNorm + ReLU on 16-row tiles: wave = row tile.
+// Output position p = S_ j + e: class e uses the taps with (e + pad - tap) % S_ == 0 at source column
+// j + (e + pad - tap) / S_ -- a dense GEMM per tap.  Only the positions [p0, p0 + Ln) that the next layer reads are
+// produced (the crops of network.py:96-97 drop the rest: with them every class is a whole number of column groups).
+template <int TAPS, int S_, int NCT>
+__device__ __forceinline__ void sf_convT16(const float* af, float* lds, int src, int lsi, int dst, int lsd, int Lout,
+                                           int p0, int Ln) {
+    const int tid_ = sf_tid();
+    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), q = lane >> 4, j = lane & 15;
     constexpr int PAD = S_ / 2;
     const int pend = min(Lout, p0 + Ln);
-    int ucount = 0;
-    bool pf = NQN > 0;
-    const f32x4* pn = (const f32x4*)tile_next + lane;
+    const int row = 16 * wave + 4 * q;
 #pragma unroll
     for (int e = 0; e < S_; ++e) {
         const int j0 = p0 > e ? (p0 - e + S_ - 1) / S_ : 0;
         const int nj = (pend - e + S_ - 1) / S_ - j0;
-        const int tiles = (nj + 31) >> 5;
-        for (int jt = 0; jt < tiles; ++jt, ++ucount) {
-            if ((ucount & 1) != (wave >> 1)) continue;
-            f32x16 acc;
+        const int ng = (nj + 16 * NCT - 1) / (16 * NCT);
+        for (int g = 0; g < ng; ++g) {
+            f32x4 acc[NCT];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int c0 = j0 + g * 16 * NCT + j;
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) {
                 constexpr int BIG = 8 * S_;
                 if ((e + PAD - tap + BIG) % S_ == 0) {
                     const int d = (e + PAD - tap + BIG) / S_ - 8;
-                    sf_mm<32, NQN>(acc, af + tap * 32, lds + src + h * lsi + 4 + j0 + jt * 32 + c + d, 2 * lsi, pf, fpn, pn);
-                    pf = false;
+                    sf_mm16<16, NCT>(acc, af + tap * 16, lds + src + q * lsi + 4 + c0 + d, 4 * lsi);
                 }
             }
-            const int p = S_ * (j0 + jt * 32 + c) + e;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float v = fmaxf(acc[r] + af[TAPS * 32 + r], 0.f);
-                if (p < pend) lds[dst + row * lsd + 4 + p] = v;
+            for (int ct = 0; ct < NCT; ++ct) {
+                const int p = S_ * (c0 + 16 * ct) + e;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = fmaxf(acc[ct][r] + af[TAPS * 16 + r], 0.f);
+                    if (p < pend) lds[dst + (row + r) * lsd + 4 + p] = v;
+                }
             }
         }
-    }
-    if constexpr (NQN > 0) {
-        if (pf) sf_load<NQN>(fpn, tile_next, lane);
     }
 }
 
@@ -311,7 +394,7 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* skip = A.scratch + (size_t)blockIdx.x * SF_SKIP;
     float* sk0 = skip, *sk1 = sk0 + 8192, *sk2 = sk1 + 16384, *sk3 = sk2 + 8192, *sk4 = sk3 + 8192;
-    float fs[176], fp[176];                      // compute set / staging set (A fragments + 16 bias values of one row tile)
+    float fs[84], fp[84];                        // compute set / staging set (A fragments + bias values of a wave's row tile(s))
     const int Cin = A.Cin;
 
     // first-conv weights: resident for the whole kernel
@@ -438,9 +521,10 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
             if (it == 1) { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); SF_STAMP(28); }
 #endif
             {
-                const int off_ = it < 3 ? A.o_pw[2 + it] : (it < 6 ? A.o_gi : A.o_fg);      // it = 6: FGRU.conv (128 -> 64)
-                const int til_ = it < 3 ? wave : (it < 6 ? 4 * (it - 3) + wave : (wave & 1));
-                SF_REQUEST(20, off_, til_);
+                // it = 6: FGRU.conv (128 -> 64) as four 16-row tiles of 9 quads (the request reads 20: inside the blob)
+                const int off_ = it < 3 ? A.o_pw[2 + it] + wave * 5120
+                                        : (it < 6 ? A.o_gi + (4 * (it - 3) + wave) * 5120 : A.o_fg + wave * 2304);
+                SF_REQUEST(20, off_, 0);
             }
             if (it == 1) SF_STAMP(29);
             if (enc) sf_pw<64, 0, 4>(fs, lds, SF_R0, LSA, 0, 0, 0, SF_R1A, LSA, L, 128, 0, true);
@@ -533,21 +617,21 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
             SF_SYNC();
             SF_STAMP(8);
             // FGRU.conv (128 -> 64) + BN + ReLU
-            SF_TAKE(20);
-            SF_REQUEST(12, A.o_dpw[0], wave & 1);                             // decoder.0 pw: 64 -> 64
-            sf_pw<64, 0, 2>(fs, lds, SF_R0, LSA, 0, 0, 0, SF_R1A, LSA, 16, 64, 0, true);
+            SF_TAKE(9);
+            SF_REQUEST(5, A.o_dpw[0], wave);                                  // decoder.0 pw: 64 -> 64
+            sf_pw16<32, 0, 1, false>(fs, lds, SF_R0, LSA, 0, 0, 0, SF_R1A, LSA, 16, 64, true);
             sf_guards(lds, SF_R1A, 64, LSA, 16);
             SF_SYNC();
             // ---------------- decoder.0 (FirstTrCNN): pw 64 -> 64, ConvT k3 s2 -> L 31            network.py:60-76
-            SF_TAKE(12);
-            SF_REQUEST(28, A.o_ct[0], wave & 1);
-            sf_pw<32, 0, 2>(fs, lds, SF_R1A, LSA, 0, 0, 0, SF_R1B, LSA, 16, 64, 0, true);
+            SF_TAKE(5);
+            SF_REQUEST(13, A.o_ct[0], wave);
+            sf_pw16<16, 0, 1, false>(fs, lds, SF_R1A, LSA, 0, 0, 0, SF_R1B, LSA, 16, 64, true);
             sf_guards(lds, SF_R1B, 64, LSA, 16);
             SF_SYNC();
             sf_restore(lds, SF_R0, LSA, sk4, 128, 3);
-            SF_TAKE(28);
-            SF_REQUEST(28, A.o_dpw[1], wave & 1);                             // decoder.1 pw: 192 -> 64
-            sf_convT<3, 2>(fs, lds, SF_R1B, LSA, SF_R1A, LSA, 31, 0, 31);
+            SF_TAKE(13);
+            SF_REQUEST(13, A.o_dpw[1], wave);                                 // decoder.1 pw: 192 -> 64
+            sf_convT16<3, 2, 1>(fs, lds, SF_R1B, LSA, SF_R1A, LSA, 31, 0, 31);
             sf_guards(lds, SF_R1A, 64, LSA, 31);
             SF_SYNC();
         }
@@ -561,12 +645,21 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
         for (int i = 1; i <= 4; ++i) {
             const int P = i == 1 ? 32 : (i == 4 ? 128 : 64);
             const int Lo = i == 1 ? 65 : (i == 2 ? 66 : (i == 3 ? 129 : 130));
-            SF_TAKE(28);
-            // same load sequence in every iteration (see the encoder loop): 44 quads are requested also for the 3-tap
-            // layers (28 used; the tile stride in the blob is that of the layer's own fragment count)
-            sf_load<44>(fp, blob + A.o_ct[i] + (size_t)(wave & 1) * (((i & 1) ? 44 : 28) * 256), lane);
+            SF_TAKE(13);
+            // same load sequence in every iteration (see the encoder loop): 21 quads are requested also for the 3-tap
+            // layers (13 used; the tile stride in the blob is that of the layer's own fragment count)
+            sf_load<21>(fp, blob + A.o_ct[i] + (size_t)wave * (((i & 1) ? 21 : 13) * 256), lane);
             __builtin_amdgcn_sched_barrier(0);
-            sf_pw<32, 64, 2>(fs, lds, SF_R1A, LSA, i == 1 ? 0 : 1, SF_R0, LSA, SF_R1B, LSA, P, 64, 0, true);
+#ifdef SF_STAMPS
+#ifndef SF_COFF
+#define SF_COFF 1
+#endif
+            sf_pw16<16, 32, 2, false>(fs, lds, SF_R1A, LSA, i == 1 ? 0 : SF_COFF, SF_R0, LSA, SF_R1B, LSA, P, 64, true,
+                                      (i == 4 && blockIdx.x == 0 && n == 0)
+                                          ? (long long*)(A.scratch + (size_t)gridDim.x * SF_SKIP) + 32 : nullptr);
+#else
+            sf_pw16<16, 32, 2, false>(fs, lds, SF_R1A, LSA, i == 1 ? 0 : 1, SF_R0, LSA, SF_R1B, LSA, P, 64, true);
+#endif
             sf_guards(lds, SF_R1B, 64, LSA, P);
             SF_SYNC();
             SF_STAMP(13 + 2 * i);                             // 15, 17, 19, 21: pointwise conv of block i done
@@ -576,14 +669,14 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
             const float* skn = i == 1 ? sk3 : (i == 2 ? sk2 : (i == 3 ? sk1 : sk0));
             const int skC = i == 4 ? 64 : 128, sklq = i <= 2 ? 4 : 5;
             sf_restore_request(rr, skn, skC, sklq);
-            SF_TAKE(44);
-            // next pw: decoder.(i+1) 192 -> 64 (28 quads per tile), or decoder.5 128 -> 8 (one padded tile of 20 quads)
-            sf_load<28>(fp, blob + A.o_dpw[i + 1] + (size_t)(i < 4 ? (wave & 1) : 0) * (28 * 256), lane);
+            SF_TAKE(21);
+            // next pw: decoder.(i+1) 192 -> 64 (13 quads per 16-row tile), or decoder.5 128 -> 8 (one padded tile of 9 quads)
+            sf_load<13>(fp, blob + A.o_dpw[i + 1] + (size_t)(i < 4 ? wave : 0) * (13 * 256), lane);
             __builtin_amdgcn_sched_barrier(0);
             // the consumer (next block / decoder.5) reads positions [1, 1 + Pn) of this output
             const int Pn = i <= 2 ? 64 : 128;
-            if (i & 1) sf_convT<5, 2>(fs, lds, SF_R1B, LSA, SF_R1A, LSA, Lo, 1, Pn);
-            else sf_convT<3, 1>(fs, lds, SF_R1B, LSA, SF_R1A, LSA, Lo, 1, Pn);
+            if (i & 1) sf_convT16<5, 2, 2>(fs, lds, SF_R1B, LSA, SF_R1A, LSA, Lo, 1, Pn);
+            else sf_convT16<3, 1, 2>(fs, lds, SF_R1B, LSA, SF_R1A, LSA, Lo, 1, Pn);
             sf_restore_commit(rr, lds, SF_R0, LSA, skC, sklq);
             sf_guards(lds, SF_R1A, 64, LSA, Lo);
             SF_SYNC();
@@ -592,8 +685,8 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
         SF_STAMP(13);
         {   // ---------------- decoder.5 (LastTrCNN): pw 128 -> 8 (+BN+ReLU), ConvT 8 -> 8 k5 s2 -> 257, linear
             //                                                                                   network.py:102-120
-            SF_TAKE(20);
-            sf_pw<32, 32, 1>(fs, lds, SF_R1A, LSA, 1, SF_R0, LSA, SF_R1B, LSA, 128, 8, 0, true);
+            SF_TAKE(9);
+            sf_pw16<16, 16, 2, true>(fs, lds, SF_R1A, LSA, 1, SF_R0, LSA, SF_R1B, LSA, 128, 8, true);
             sf_guards(lds, SF_R1B, 8, LSA, 128);
             sf_stage(lds, SF_DWB, blob + A.o_last, 8 * 8 * 5 + 8);       // [ci][co][k], bias
             request_x(n + gridDim.x);                                       // next frame's features, in flight over the tail
@@ -619,7 +712,7 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
 
 }  // namespace
 
-extern "C" size_t trunet_stream_fwd_scratch_floats(int grid) { return (size_t)grid * SF_SKIP + 64; }
+extern "C" size_t trunet_stream_fwd_scratch_floats(int grid) { return (size_t)grid * SF_SKIP + 256; }
 extern "C" int trunet_stream_fwd_grid(int N) { return N < 2 * TRUNET_NUM_CU ? (N < TRUNET_NUM_CU ? N : TRUNET_NUM_CU) : TRUNET_NUM_CU; }
 
 extern "C" int trunet_stream_fwd(const float* x, float* y, const float* blob, const int32_t* h_offsets, int n_offsets,

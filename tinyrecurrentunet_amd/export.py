@@ -47,6 +47,29 @@ def _frag_tiles(Wm, bias):
     return np.concatenate(out)
 
 
+def _frag_tiles16(Wm, bias):
+    """Wm (M, K) float64, bias (M,): per 16-row tile [K/16 quads of A fragments][1 quad of bias], each quad [64 lanes][4].
+    Lane l holds A[row l & 15][k = 4 kq + (l >> 4)] (v_mfma_f32_16x16x4_f32 A operand) and the bias of the 4 rows of its
+    accumulator registers (row = 4 (l >> 4) + r)."""
+    M, K = Wm.shape
+    nrt = (M + 15) // 16
+    KQ = (K + 15) // 16 * 4
+    Wp = np.zeros((nrt * 16, 4 * KQ))
+    Wp[:M, :K] = Wm
+    bp = np.zeros(nrt * 16)
+    bp[:M] = bias
+    lane = np.arange(64)
+    out = []
+    for rt in range(nrt):
+        rows = rt * 16 + (lane & 15)
+        kq = np.arange(KQ)
+        A = Wp[rows[None, :], 4 * kq[:, None] + (lane >> 4)[None, :]]        # (KQ, 64)
+        A = A.reshape(KQ // 4, 4, 64).transpose(0, 2, 1)                      # (quad, lane, 4)
+        Bq = bp[rt * 16 + 4 * (lane >> 4)[:, None] + np.arange(4)[None, :]]   # (lane, 4)
+        out.append(np.concatenate([A.reshape(-1), Bq.reshape(-1)]))
+    return np.concatenate(out)
+
+
 def fold(net):
     """TRUNet (network.py R1 layer sizes) -> (blob float32 ndarray, offsets int32[26], C_in)"""
     sec, offs = [], []
@@ -94,18 +117,18 @@ def fold(net):
     add(np.concatenate(whh + [t(g.bias_hh_l0), t(g.bias_hh_l0_reverse)]))                          # o_whh
     sc, sh = _bn_affine(net.FGRU.conv[1])
     fc = net.FGRU.conv[0]
-    add(_frag_tiles(t(fc.weight)[:, :, 0] * sc.numpy()[:, None], t(fc.bias) * sc.numpy() + sh.numpy()))   # o_fg
+    add(_frag_tiles16(t(fc.weight)[:, :, 0] * sc.numpy()[:, None], t(fc.bias) * sc.numpy() + sh.numpy()))   # o_fg
     dpw, cts, last = [], [], None
     for i in range(6):
         seq = net.decoder[i].FirstTrCNN if i == 0 else (net.decoder[i].TrCNN if i < 5 else net.decoder[i].LastTrCNN)
         sc, sh = _bn_affine(seq[1])
-        dpw.append(_frag_tiles(t(seq[0].weight)[:, :, 0] * sc.numpy()[:, None], t(seq[0].bias) * sc.numpy() + sh.numpy()))
+        dpw.append(_frag_tiles16(t(seq[0].weight)[:, :, 0] * sc.numpy()[:, None], t(seq[0].bias) * sc.numpy() + sh.numpy()))
         ct = seq[3]
         if i < 5:
             sc, sh = _bn_affine(seq[4])
             Wt = t(ct.weight) * sc.numpy()[None, :, None]                              # (Ci, Co, k)
             A = np.concatenate([Wt[:, :, k].T for k in range(Wt.shape[2])], 1)         # (Co, k*Ci): tap-major K axis
-            cts.append(_frag_tiles(A, t(ct.bias) * sc.numpy() + sh.numpy()))
+            cts.append(_frag_tiles16(A, t(ct.bias) * sc.numpy() + sh.numpy()))
         else:
             last = np.concatenate([t(ct.weight).reshape(-1), t(ct.bias)])              # linear output layer
     for a in dpw:
@@ -136,13 +159,13 @@ class FoldedTRUNet:
         return cls(blob, offs, cin, dev)
 
     def save(self, path):
-        torch.save({"format": "trunet-folded-v1", "blob": self.blob.cpu(), "offsets": torch.tensor(self.offsets),
+        torch.save({"format": "trunet-folded-v2", "blob": self.blob.cpu(), "offsets": torch.tensor(self.offsets),
                     "cin": self.cin}, path)
 
     @classmethod
     def load(cls, path, device=None):
         d = torch.load(path, map_location="cpu", weights_only=True)
-        if d.get("format") != "trunet-folded-v1":
+        if d.get("format") != "trunet-folded-v2":
             raise L.TrunetHipError("%s is not a folded TRU-Net artefact" % path)
         return cls(d["blob"], d["offsets"].numpy(), int(d["cin"]), device)
 
