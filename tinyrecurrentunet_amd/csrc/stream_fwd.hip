@@ -181,10 +181,7 @@ __device__ __forceinline__ void sf_pw(const float* af, float* lds, int src1, int
 // acc[ct] += A(af[0..KQ)) * B for NCT column tiles of 16: S is the lane's base (row l >> 4, column l & 15), rs4 = 4 rows.
 template <int KQ, int NCT>
 __device__ __forceinline__ void sf_mm16(f32x4 (&acc)[NCT], const float* af, const float* S, int rs4) {
-#ifndef SF_LA16
-#define SF_LA16 8
-#endif
-    constexpr int LA = SF_LA16, NT = KQ * NCT;
+    constexpr int LA = 8, NT = KQ * NCT;
     float b[NT];
     const sf_lptr S0 = sf_lds_base(S), S1 = sf_lds_base(S + (KQ > 24 ? 24 : 0) * rs4);      // 24 k-quads x 2304 B per base
 #define SF_B(x) ((x) / NCT < 24 ? S0[((x) / NCT) * rs4 + ((x) % NCT) * 16] : S1[((x) / NCT - 24) * rs4 + ((x) % NCT) * 16])
@@ -223,13 +220,9 @@ __device__ __forceinline__ void sf_pw16(const float* af, float* lds, int src1, i
         for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int c0 = g * 16 * NCT + j;
         SF_ISTAMP();
-#if !defined(SF_NOMM) || SF_NOMM != 1
         sf_mm16<KQ1, NCT>(acc, af, lds + src1 + q * ls1 + 4 + c0 + coff1, 4 * ls1);
-#endif
         SF_ISTAMP();
-#if !defined(SF_NOMM) || SF_NOMM != 2
         if constexpr (KQ2 > 0) sf_mm16<KQ2, NCT>(acc, af + KQ1, lds + src2 + q * ls2 + 4 + c0, 4 * ls2);
-#endif
         SF_ISTAMP();
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
@@ -651,10 +644,7 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
             sf_load<21>(fp, blob + A.o_ct[i] + (size_t)wave * (((i & 1) ? 21 : 13) * 256), lane);
             __builtin_amdgcn_sched_barrier(0);
 #ifdef SF_STAMPS
-#ifndef SF_COFF
-#define SF_COFF 1
-#endif
-            sf_pw16<16, 32, 2, false>(fs, lds, SF_R1A, LSA, i == 1 ? 0 : SF_COFF, SF_R0, LSA, SF_R1B, LSA, P, 64, true,
+            sf_pw16<16, 32, 2, false>(fs, lds, SF_R1A, LSA, i == 1 ? 0 : 1, SF_R0, LSA, SF_R1B, LSA, P, 64, true,
                                       (i == 4 && blockIdx.x == 0 && n == 0)
                                           ? (long long*)(A.scratch + (size_t)gridDim.x * SF_SKIP) + 32 : nullptr);
 #else
@@ -688,21 +678,46 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
             SF_TAKE(9);
             sf_pw16<16, 16, 2, true>(fs, lds, SF_R1A, LSA, 1, SF_R0, LSA, SF_R1B, LSA, 128, 8, true);
             sf_guards(lds, SF_R1B, 8, LSA, 128);
-            sf_stage(lds, SF_DWB, blob + A.o_last, 8 * 8 * 5 + 8);       // [ci][co][k], bias
+            // ConvT weights [ci][co][k] + bias, staged as [co / 4][ci][k][co % 4]: a thread's four output channels of one
+            // (ci, tap) are one wave-uniform 16-byte read
+            for (int i = tid; i < 8 * 8 * 5 + 8; i += SF_T) {
+                int d = i;
+                if (i < 320) {
+                    const int ci = i / 40, r = i - ci * 40, co = r / 5, k = r - co * 5;
+                    d = (((co >> 2) * 8 + ci) * 5 + k) * 4 + (co & 3);
+                }
+                lds[SF_DWB + d] = blob[A.o_last + i];
+            }
             request_x(n + gridDim.x);                                       // next frame's features, in flight over the tail
             SF_SYNC();
             float* yg = A.y + (size_t)n * 8 * 257;
-            for (int o = tid; o < 8 * 257; o += SF_T) {
-                const int co = o / 257, p = o - co * 257;
-                float v = lds[SF_DWB + 320 + co];
-                // taps with (p + 1 - k) even: k = (p + 1) & 1, +2, +4; source position (p + 1 - k) / 2
-                for (int k = (p + 1) & 1; k < 5; k += 2) {
-                    const int q = (p + 1 - k) >> 1;              // guards cover q = -1 and q = 128
-                    const float* in = lds + SF_R1B + 4 + q;
+            {
+                // thread = (source position j, four output channels): outputs p = 2 j (taps 1, 3 at q = j, j - 1) and
+                // p = 2 j + 1 (taps 0, 2, 4 at q = j + 1, j, j - 1); the guards cover q = -1 and q = 128.  24 input reads and
+                // 40 weight reads for 160 FMAs (the per-output form read two LDS words per FMA)
+                const int t_ = sf_tid();
+                const int j = t_ & 127, cg = __builtin_amdgcn_readfirstlane(t_ >> 7);
+                const float* in = lds + SF_R1B + 4 + j;
+                const f32x4* W4 = (const f32x4*)(lds + SF_DWB) + cg * 40;
+                f32x4 a0 = *(const f32x4*)(lds + SF_DWB + 320 + 4 * cg), a1 = a0;
 #pragma unroll
-                    for (int ci = 0; ci < 8; ++ci) v = fmaf(lds[SF_DWB + (ci * 8 + co) * 5 + k], in[ci * LSA], v);
+                for (int ci = 0; ci < 8; ++ci) {
+                    const float xm = in[ci * LSA - 1], x0 = in[ci * LSA], xp = in[ci * LSA + 1];
+                    const f32x4 w0 = W4[ci * 5], w1 = W4[ci * 5 + 1], w2 = W4[ci * 5 + 2], w3 = W4[ci * 5 + 3],
+                                w4 = W4[ci * 5 + 4];
+                    a0 += w1 * x0 + w3 * xm;
+                    a1 += w0 * xp + w2 * x0 + w4 * xm;
                 }
-                yg[o] = v;
+                float* yb = yg + (size_t)(4 * cg) * 257 + 2 * j;
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) { yb[c4 * 257] = a0[c4]; yb[c4 * 257 + 1] = a1[c4]; }
+                if (t_ < 8) {               // p = 256: taps 1 (q = 128: zero guard) and 3 (q = 127)
+                    float v = lds[SF_DWB + 320 + t_];
+#pragma unroll
+                    for (int ci = 0; ci < 8; ++ci)
+                        v = fmaf(lds[SF_DWB + (((t_ >> 2) * 8 + ci) * 5 + 3) * 4 + (t_ & 3)], lds[SF_R1B + ci * LSA + 4 + 127], v);
+                    yg[t_ * 257 + 256] = v;
+                }
             }
             SF_SYNC();
         }
