@@ -39,6 +39,10 @@ __device__ __forceinline__ float sf_sigmoid(float x) { return 1.f / (1.f + expf(
 __device__ __forceinline__ float sf_tanh(float x) { return tanhf(x); }
 #endif
 
+__device__ __forceinline__ float sf_dpp_xor1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+
 // The per-lane addresses of a layer's epilogue depend only on the thread index, so the compiler would compute them for
 // all layers once, before the frame loop, and keep (spill) hundreds of them: every layer re-derives them from an opaque
 // copy of the thread index instead.
@@ -199,10 +203,11 @@ __device__ __forceinline__ void sf_mm16(f32x4 (&acc)[NCT], const float* af, cons
 
 // Pointwise conv (+ folded BatchNorm) over one or two sources, M <= 64 rows as 16-row tiles.  SPLIT = false: wave = row
 // tile, every wave covers all P columns; SPLIT = true (M <= 16): one row tile, the waves split the column groups.
-// NCT column tiles of 16 per group (1 for the 16-position layers, else 2).
-template <int KQ1, int KQ2, int NCT, bool SPLIT>
+// NCT column tiles of 16 per group (1 for the 16-position layers, else 2).  FULL: P is a multiple of the group width and
+// M of 16 (no bounds checks in the epilogue).  ReLU always (every user is conv + BatchNorm + ReLU).
+template <int KQ1, int KQ2, int NCT, bool SPLIT, bool FULL>
 __device__ __forceinline__ void sf_pw16(const float* af, float* lds, int src1, int ls1, int coff1, int src2, int ls2, int dst,
-                                        int lsd, int P, int M, bool relu, long long* stamps = nullptr) {
+                                        int lsd, int P, int M, long long* stamps = nullptr) {
     const int tid_ = sf_tid();
     const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), q = lane >> 4, j = lane & 15;
     const int row = (SPLIT ? 0 : 16 * wave) + 4 * q;
@@ -229,9 +234,8 @@ __device__ __forceinline__ void sf_pw16(const float* af, float* lds, int src1, i
             const int col = c0 + 16 * ct;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float v = acc[ct][r] + af[KQ1 + KQ2 + r];
-                if (relu) v = fmaxf(v, 0.f);
-                if (col < P && row + r < M) lds[dst + (row + r) * lsd + 4 + col] = v;
+                const float v = fmaxf(acc[ct][r] + af[KQ1 + KQ2 + r], 0.f);
+                if (FULL || (col < P && row + r < M)) lds[dst + (row + r) * lsd + 4 + col] = v;
             }
         }
         SF_ISTAMP();
@@ -242,7 +246,7 @@ __device__ __forceinline__ void sf_pw16(const float* af, float* lds, int src1, i
 // Output position p = S_ j + e: class e uses the taps with (e + pad - tap) % S_ == 0 at source column
 // j + (e + pad - tap) / S_ -- a dense GEMM per tap.  Only the positions [p0, p0 + Ln) that the next layer reads are
 // produced (the crops of network.py:96-97 drop the rest: with them every class is a whole number of column groups).
-template <int TAPS, int S_, int NCT>
+template <int TAPS, int S_, int NCT, bool FULL>
 __device__ __forceinline__ void sf_convT16(const float* af, float* lds, int src, int lsi, int dst, int lsd, int Lout,
                                            int p0, int Ln) {
     const int tid_ = sf_tid();
@@ -274,7 +278,7 @@ __device__ __forceinline__ void sf_convT16(const float* af, float* lds, int src,
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float v = fmaxf(acc[ct][r] + af[TAPS * 16 + r], 0.f);
-                    if (p < pend) lds[dst + (row + r) * lsd + 4 + p] = v;
+                    if (FULL || p < pend) lds[dst + (row + r) * lsd + 4 + p] = v;
                 }
             }
         }
@@ -592,7 +596,9 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
                     n0_ = fmaf(wn[4 * i + 2], hv[i][2], n0_); n1 = fmaf(wn[4 * i + 3], hv[i][3], n1);
                 }
                 float gr = r0 + r1, gz = z0 + z1, gn = n0_ + n1;
-                gr += __shfl_xor(gr, 1); gz += __shfl_xor(gz, 1); gn += __shfl_xor(gn, 1);      // the other K-half
+                // the other K-half: lane ^ 1 through DPP (quad_perm [1,0,3,2]); __shfl_xor compiles to ds_bpermute, an LDS
+                // round trip on the critical path of every step
+                gr += sf_dpp_xor1(gr); gz += sf_dpp_xor1(gz); gn += sf_dpp_xor1(gn);
                 const float r = sf_sigmoid(gir + gr + br);
                 const float z = sf_sigmoid(giz + gz + bz);
                 const float nn = sf_tanh(fmaf(r, gn + bn, gin));
@@ -612,19 +618,19 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
             // FGRU.conv (128 -> 64) + BN + ReLU
             SF_TAKE(9);
             SF_REQUEST(5, A.o_dpw[0], wave);                                  // decoder.0 pw: 64 -> 64
-            sf_pw16<32, 0, 1, false>(fs, lds, SF_R0, LSA, 0, 0, 0, SF_R1A, LSA, 16, 64, true);
+            sf_pw16<32, 0, 1, false, true>(fs, lds, SF_R0, LSA, 0, 0, 0, SF_R1A, LSA, 16, 64);
             sf_guards(lds, SF_R1A, 64, LSA, 16);
             SF_SYNC();
             // ---------------- decoder.0 (FirstTrCNN): pw 64 -> 64, ConvT k3 s2 -> L 31            network.py:60-76
             SF_TAKE(5);
             SF_REQUEST(13, A.o_ct[0], wave);
-            sf_pw16<16, 0, 1, false>(fs, lds, SF_R1A, LSA, 0, 0, 0, SF_R1B, LSA, 16, 64, true);
+            sf_pw16<16, 0, 1, false, true>(fs, lds, SF_R1A, LSA, 0, 0, 0, SF_R1B, LSA, 16, 64);
             sf_guards(lds, SF_R1B, 64, LSA, 16);
             SF_SYNC();
             sf_restore(lds, SF_R0, LSA, sk4, 128, 3);
             SF_TAKE(13);
             SF_REQUEST(13, A.o_dpw[1], wave);                                 // decoder.1 pw: 192 -> 64
-            sf_convT16<3, 2, 1>(fs, lds, SF_R1B, LSA, SF_R1A, LSA, 31, 0, 31);
+            sf_convT16<3, 2, 1, false>(fs, lds, SF_R1B, LSA, SF_R1A, LSA, 31, 0, 31);
             sf_guards(lds, SF_R1A, 64, LSA, 31);
             SF_SYNC();
         }
@@ -644,11 +650,11 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
             sf_load<21>(fp, blob + A.o_ct[i] + (size_t)wave * (((i & 1) ? 21 : 13) * 256), lane);
             __builtin_amdgcn_sched_barrier(0);
 #ifdef SF_STAMPS
-            sf_pw16<16, 32, 2, false>(fs, lds, SF_R1A, LSA, i == 1 ? 0 : 1, SF_R0, LSA, SF_R1B, LSA, P, 64, true,
-                                      (i == 4 && blockIdx.x == 0 && n == 0)
-                                          ? (long long*)(A.scratch + (size_t)gridDim.x * SF_SKIP) + 32 : nullptr);
+            sf_pw16<16, 32, 2, false, true>(fs, lds, SF_R1A, LSA, i == 1 ? 0 : 1, SF_R0, LSA, SF_R1B, LSA, P, 64,
+                                            (i == 4 && blockIdx.x == 0 && n == 0)
+                                                ? (long long*)(A.scratch + (size_t)gridDim.x * SF_SKIP) + 32 : nullptr);
 #else
-            sf_pw16<16, 32, 2, false>(fs, lds, SF_R1A, LSA, i == 1 ? 0 : 1, SF_R0, LSA, SF_R1B, LSA, P, 64, true);
+            sf_pw16<16, 32, 2, false, true>(fs, lds, SF_R1A, LSA, i == 1 ? 0 : 1, SF_R0, LSA, SF_R1B, LSA, P, 64);
 #endif
             sf_guards(lds, SF_R1B, 64, LSA, P);
             SF_SYNC();
@@ -665,8 +671,8 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
             __builtin_amdgcn_sched_barrier(0);
             // the consumer (next block / decoder.5) reads positions [1, 1 + Pn) of this output
             const int Pn = i <= 2 ? 64 : 128;
-            if (i & 1) sf_convT16<5, 2, 2>(fs, lds, SF_R1B, LSA, SF_R1A, LSA, Lo, 1, Pn);
-            else sf_convT16<3, 1, 2>(fs, lds, SF_R1B, LSA, SF_R1A, LSA, Lo, 1, Pn);
+            if (i & 1) sf_convT16<5, 2, 2, true>(fs, lds, SF_R1B, LSA, SF_R1A, LSA, Lo, 1, Pn);
+            else sf_convT16<3, 1, 2, true>(fs, lds, SF_R1B, LSA, SF_R1A, LSA, Lo, 1, Pn);
             sf_restore_commit(rr, lds, SF_R0, LSA, skC, sklq);
             sf_guards(lds, SF_R1A, 64, LSA, Lo);
             SF_SYNC();
@@ -676,7 +682,7 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
         {   // ---------------- decoder.5 (LastTrCNN): pw 128 -> 8 (+BN+ReLU), ConvT 8 -> 8 k5 s2 -> 257, linear
             //                                                                                   network.py:102-120
             SF_TAKE(9);
-            sf_pw16<16, 16, 2, true>(fs, lds, SF_R1A, LSA, 1, SF_R0, LSA, SF_R1B, LSA, 128, 8, true);
+            sf_pw16<16, 16, 2, true, false>(fs, lds, SF_R1A, LSA, 1, SF_R0, LSA, SF_R1B, LSA, 128, 8);
             sf_guards(lds, SF_R1B, 8, LSA, 128);
             // ConvT weights [ci][co][k] + bias, staged as [co / 4][ci][k][co % 4]: a thread's four output channels of one
             // (ci, tap) are one wave-uniform 16-byte read
