@@ -204,13 +204,13 @@ __device__ __forceinline__ void sf_mm16(f32x4 (&acc)[NCT], const float* af, cons
 // Pointwise conv (+ folded BatchNorm) over one or two sources, M <= 64 rows as 16-row tiles.  SPLIT = false: wave = row
 // tile, every wave covers all P columns; SPLIT = true (M <= 16): one row tile, the waves split the column groups.
 // NCT column tiles of 16 per group (1 for the 16-position layers, else 2).  FULL: P is a multiple of the group width and
-// M of 16 (no bounds checks in the epilogue).  ReLU always (every user is conv + BatchNorm + ReLU).
-template <int KQ1, int KQ2, int NCT, bool SPLIT, bool FULL>
+// M of 16 (no bounds checks in the epilogue).  rowbase >= 0: first output row of this wave's tile (default 16 x wave).
+template <int KQ1, int KQ2, int NCT, bool SPLIT, bool FULL, bool RELU = true>
 __device__ __forceinline__ void sf_pw16(const float* af, float* lds, int src1, int ls1, int coff1, int src2, int ls2, int dst,
-                                        int lsd, int P, int M, long long* stamps = nullptr) {
+                                        int lsd, int P, int M, long long* stamps = nullptr, int rowbase = -1) {
     const int tid_ = sf_tid();
     const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), q = lane >> 4, j = lane & 15;
-    const int row = (SPLIT ? 0 : 16 * wave) + 4 * q;
+    const int row = (rowbase >= 0 ? rowbase : (SPLIT ? 0 : 16 * wave)) + 4 * q;
     int sidx = 0;
 #ifdef SF_STAMPS
 #define SF_ISTAMP() do { if (stamps && tid_ == 0) stamps[sidx++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
@@ -234,7 +234,8 @@ __device__ __forceinline__ void sf_pw16(const float* af, float* lds, int src1, i
             const int col = c0 + 16 * ct;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v = fmaxf(acc[ct][r] + af[KQ1 + KQ2 + r], 0.f);
+                float v = acc[ct][r] + af[KQ1 + KQ2 + r];
+                if (RELU) v = fmaxf(v, 0.f);
                 if (FULL || (col < P && row + r < M)) lds[dst + (row + r) * lsd + 4 + col] = v;
             }
         }
@@ -500,48 +501,58 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
             sf_save(lds, SF_R0, LSA, sk1, 128, 5);
         }
         SF_STAMP(2);
-        // encoder.2 .. encoder.5 (128 -> 128 pointwise, then depthwise k5 s2 / k3 s1 / k5 s2 / k3 s2) and the three
-        // 128-row passes of the GRU input projection (384 x 128, both directions; network.py:45-58,149) share ONE
-        // unrolled 128 x 128 MFMA body: it = 0..3 encoder blocks, it = 4..6 projection rows 128 (it - 4) ...
-        for (int it = 0; it < 7; ++it) {
-            const bool enc = it < 4;
-            const int L = it == 0 ? 128 : (it <= 2 ? 64 : (it == 3 ? 32 : 16));      // positions of this layer's input
+        // encoder.2 .. encoder.5: 128 -> 128 pointwise (ONE unrolled 128 x 128 MFMA body), then depthwise k5 s2 / k3 s1 /
+        // k5 s2 / k3 s2                                                                       network.py:24-43
+        for (int it = 0; it < 4; ++it) {
+            const int L = it == 0 ? 128 : (it <= 2 ? 64 : 32);      // positions of this layer's input
             // (every iteration issues the SAME sequence of global loads, selected by offsets and not by branches: with
             // divergent paths hipcc's s_waitcnt pass merges pessimistically at the loop header and makes the MFMAs
             // below wait for the fragments that were only just requested for the NEXT layer)
             float dwr[3];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) dwr[j] = blob[A.o_dw[enc ? 1 + it : 4] + tid + SF_T * j];
+            for (int j = 0; j < 3; ++j) dwr[j] = blob[A.o_dw[1 + it] + tid + SF_T * j];
             if (it == 1) SF_STAMP(27);
             SF_TAKE(20);
 #ifdef SF_STAMPS
             if (it == 1) { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); SF_STAMP(28); }
 #endif
             {
-                // it = 6: FGRU.conv (128 -> 64) as four 16-row tiles of 9 quads (the request reads 20: inside the blob)
-                const int off_ = it < 3 ? A.o_pw[2 + it] + wave * 5120
-                                        : (it < 6 ? A.o_gi + (4 * (it - 3) + wave) * 5120 : A.o_fg + wave * 2304);
+                // next: encoder.(3 + it) (20 quads per 32-row tile), or the first projection pass (two 16-row tiles = 18
+                // quads; the request reads 20: inside the blob)
+                const int off_ = it < 3 ? A.o_pw[2 + it] + wave * 5120 : A.o_gi + 2 * wave * 2304;
                 SF_REQUEST(20, off_, 0);
             }
             if (it == 1) SF_STAMP(29);
-            if (enc) sf_pw<64, 0, 4>(fs, lds, SF_R0, LSA, 0, 0, 0, SF_R1A, LSA, L, 128, 0, true);
-            else sf_pw<64, 0, 4>(fs, lds, SF_R0, LSA, 0, 0, 0, SF_R1A, LSG, 16, 128, 128 * (it - 4), false);
+            sf_pw<64, 0, 4>(fs, lds, SF_R0, LSA, 0, 0, 0, SF_R1A, LSA, L, 128, 0, true);
             if (it == 1) SF_STAMP(30);
-            if (enc) {
-                sf_guards(lds, SF_R1A, 128, LSA, L);
+            sf_guards(lds, SF_R1A, 128, LSA, L);
 #pragma unroll
-                for (int j = 0; j < 3; ++j) lds[SF_DWB + tid + SF_T * j] = dwr[j];
-                SF_SYNC();
-                if (it == 1) sf_dw<3, 1>(lds, SF_R1A, LSA, SF_R0, LSA, SF_DWB, 128, 64);
-                else if (it == 3) sf_dw<3, 2>(lds, SF_R1A, LSA, SF_R0, LSA, SF_DWB, 128, 16);
-                else sf_dw<5, 2>(lds, SF_R1A, LSA, SF_R0, LSA, SF_DWB, 128, L >> 1);
-                const int Lo = it == 1 ? 64 : (L >> 1);
-                sf_guards(lds, SF_R0, 128, LSA, Lo);
-                SF_SYNC();
-                if (it == 1) SF_STAMP(31);
-                if (it < 3) sf_save(lds, SF_R0, LSA, it == 0 ? sk2 : (it == 1 ? sk3 : sk4), 128, it == 2 ? 3 : 4);
+            for (int j = 0; j < 3; ++j) lds[SF_DWB + tid + SF_T * j] = dwr[j];
+            SF_SYNC();
+            if (it == 1) sf_dw<3, 1>(lds, SF_R1A, LSA, SF_R0, LSA, SF_DWB, 128, 64);
+            else if (it == 3) sf_dw<3, 2>(lds, SF_R1A, LSA, SF_R0, LSA, SF_DWB, 128, 16);
+            else sf_dw<5, 2>(lds, SF_R1A, LSA, SF_R0, LSA, SF_DWB, 128, L >> 1);
+            const int Lo = it == 1 ? 64 : (L >> 1);
+            sf_guards(lds, SF_R0, 128, LSA, Lo);
+            SF_SYNC();
+            if (it == 1) SF_STAMP(31);
+            if (it < 3) sf_save(lds, SF_R0, LSA, it == 0 ? sk2 : (it == 1 ? sk3 : sk4), 128, it == 2 ? 3 : 4);
+            SF_STAMP(3 + it);
+        }
+        // GRU input projection (384 x 128, both directions; network.py:45-58,149) over the 16 positions: 24 row tiles of
+        // 16 (one exact 16 x 16 tile each; 32-row tiles were half empty), three passes of two tiles per wave
+        for (int ps = 0; ps < 3; ++ps) {
+            SF_TAKE(18);
+            {
+                // next pass, or FGRU.conv (128 -> 64: four 16-row tiles of 9 quads; the request reads 18)
+                const int off_ = ps < 2 ? A.o_gi + (8 * (ps + 1) + 2 * wave) * 2304 : A.o_fg + wave * 2304;
+                SF_REQUEST(18, off_, 0);
             }
-            SF_STAMP(it < 4 ? 3 + it : 6 + it);              // 3..6 encoder.2-5, 10..12 projection passes
+#pragma unroll
+            for (int rtl = 0; rtl < 2; ++rtl)
+                sf_pw16<32, 0, 1, false, true, false>(fs + 36 * rtl, lds, SF_R0, LSA, 0, 0, 0, SF_R1A, LSG, 16, 384, nullptr,
+                                                      16 * (8 * ps + 2 * wave + rtl));
+            SF_STAMP(10 + ps);
         }
         SF_SYNC();
 #if defined(SF_ABL) && (SF_ABL & 4)      // diagnostic: encoder + projection only (does a smaller code footprint stay in the I-cache?)

@@ -102,7 +102,7 @@ def fold(net):
     g = net.FGRU.GRU
     Wih = np.concatenate([t(g.weight_ih_l0), t(g.weight_ih_l0_reverse)], 0)
     bih = np.concatenate([t(g.bias_ih_l0), t(g.bias_ih_l0_reverse)], 0)
-    add(_frag_tiles(Wih, bih))                                                         # o_gi
+    add(_frag_tiles16(Wih, bih))                                                       # o_gi
     # recurrence weights in the order the kernel's threads read them: [direction][24 quads][128 threads][4]; thread
     # t = 2 j + kh owns the K-half [32 kh, 32 kh + 32) of rows j (r), 64 + j (z), 128 + j (n): quad 8 g + i holds
     # W_hh[64 g + j][32 kh + 4 i .. + 3]; then b_hh of both directions
