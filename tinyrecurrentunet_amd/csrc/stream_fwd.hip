@@ -660,6 +660,16 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
             // layers (13 used; the tile stride in the blob is that of the layer's own fragment count)
             sf_load<21>(fp, blob + A.o_ct[i] + (size_t)wave * (((i & 1) ? 21 : 13) * 256), lane);
             __builtin_amdgcn_sched_barrier(0);
+            // skip tensor of the next block: enc3 (L 64), enc2 (L 64), enc1 (L 128), enc0 (64 x 128): requested a whole
+            // block ahead (all workgroups restore at about the same time and the 45 MB of skip tensors live in the
+            // Infinity Cache, not in the L2: the burst needs the time), written to R0 after the ConvT (R0's current
+            // content, this block's skip, is last read by the pointwise conv below).  Issued AFTER the ConvT's fragments:
+            // vmcnt retires in order, and those are needed first
+            f32x4 rr[16];
+            const float* skn = i == 1 ? sk3 : (i == 2 ? sk2 : (i == 3 ? sk1 : sk0));
+            const int skC = i == 4 ? 64 : 128, sklq = i <= 2 ? 4 : 5;
+            sf_restore_request(rr, skn, skC, sklq);
+            __builtin_amdgcn_sched_barrier(0);
 #ifdef SF_STAMPS
             sf_pw16<16, 32, 2, false, true>(fs, lds, SF_R1A, LSA, i == 1 ? 0 : 1, SF_R0, LSA, SF_R1B, LSA, P, 64,
                                             (i == 4 && blockIdx.x == 0 && n == 0)
@@ -670,12 +680,6 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
             sf_guards(lds, SF_R1B, 64, LSA, P);
             SF_SYNC();
             SF_STAMP(13 + 2 * i);                             // 15, 17, 19, 21: pointwise conv of block i done
-            // skip tensor of the next block: enc3 (L 64), enc2 (L 64), enc1 (L 128), enc0 (64 x 128): requested now,
-            // written to R0 after the ConvT (R0's current content, this block's skip, was last read before the barrier)
-            f32x4 rr[16];
-            const float* skn = i == 1 ? sk3 : (i == 2 ? sk2 : (i == 3 ? sk1 : sk0));
-            const int skC = i == 4 ? 64 : 128, sklq = i <= 2 ? 4 : 5;
-            sf_restore_request(rr, skn, skC, sklq);
             SF_TAKE(21);
             // next pw: decoder.(i+1) 192 -> 64 (13 quads per 16-row tile), or decoder.5 128 -> 8 (one padded tile of 9 quads)
             sf_load<13>(fp, blob + A.o_dpw[i + 1] + (size_t)(i < 4 ? wave : 0) * (13 * 256), lane);
