@@ -161,25 +161,12 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(const trunet_bgemm_args a
                         bf16x8 bfrag[BG_NCB];
 #pragma unroll
                         for (int cb = 0; cb < BG_NCB; ++cb) {
-                            if (mode == TRUNET_PRO_NONE) {
-                                bfrag[cb] = __builtin_bit_cast(bf16x8, r0[j][cb]);      // raw operand: no unpack / repack
-                            } else {
-                                float v[8];
-                                bf_unpack8(r0[j][cb], v);
-                                if constexpr (TWO) {
-                                    if (mode == TRUNET_PRO_BNBWD) {
-                                        float w[8];
-                                        bf_unpack8(r1[j][cb], w);
-#pragma unroll
-                                        for (int e = 0; e < 8; ++e) v[e] = fmaf(cf[e], v[e], fmaf(cf[8 + e], w[e], cf[16 + e]));
-                                    }
-                                }
-                                if (mode == TRUNET_PRO_BNRELU) {
-#pragma unroll
-                                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(cf[e], v[e], cf[8 + e]), 0.f);
-                                }
-                                bfrag[cb] = __builtin_bit_cast(bf16x8, bf_pack8(v));
+                            u32x4 fr = r0[j][cb];                                       // NONE: raw operand, no unpack / repack
+                            if constexpr (TWO) {
+                                if (mode == TRUNET_PRO_BNBWD) fr = bf_bnbwd8(fr, r1[j][cb], cf, cf + 8, cf + 16);
                             }
+                            if (mode == TRUNET_PRO_BNRELU) fr = bf_affine8<true>(fr, cf, cf + 8);
+                            bfrag[cb] = __builtin_bit_cast(bf16x8, fr);
                         }
 #pragma unroll
                         for (int t = 0; t < NRT; ++t) {
@@ -555,15 +542,9 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
                     if (SMODE == TRUNET_PRO_NONE && (sg.nchan & 7) == 0) {
                         *(u32x4*)(buf + (moct + soct_g[j]) * BW_OS + lane * 16) = r.s[j];       // raw operand
                     } else {
-                        float v[8];
-                        bf_unpack8(r.s[j], v);
                         const float* cs = Cs + soct_g[j] * 16;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            v[e] = fmaf(cs[e], v[e], cs[8 + e]);
-                            if (SMODE != TRUNET_PRO_NONE) v[e] = fmaxf(v[e], 0.f);
-                        }
-                        *(u32x4*)(buf + (moct + soct_g[j]) * BW_OS + lane * 16) = bf_pack8(v);
+                        *(u32x4*)(buf + (moct + soct_g[j]) * BW_OS + lane * 16) =
+                            bf_affine8<SMODE != TRUNET_PRO_NONE>(r.s[j], cs, cs + 8);
                     }
                 }
             }

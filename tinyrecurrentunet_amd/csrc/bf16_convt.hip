@@ -111,12 +111,8 @@ __global__ __launch_bounds__(BCT_THREADS, 1) void bconvt_bwd_kernel(const trunet
         {
             const int par = f.q & 1;
             *(u32x4*)(rawb + (par * 8 + wave) * BW_OS + lane * 16) = st.s;
-            float v[8];
-            bf_unpack8(st.s, v);
             const float* cs = Cs + wave * 16;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(cs[e], v[e], cs[8 + e]), 0.f);
-            *(u32x4*)(actb + (par * 8 + wave) * BW_OS + lane * 16) = bf_pack8(v);
+            *(u32x4*)(actb + (par * 8 + wave) * BW_OS + lane * 16) = bf_affine8<true>(st.s, cs, cs + 8);
         }
     };
     auto mma = [&](const Info& f) {
