@@ -331,7 +331,8 @@ int trunet_phm_fwd(const float* mix_ri, const float* est_ri, float* out, int64_t
 /* ---- eval-mode single-launch forward (rt.py:20-27 protocol, onnx.py:14-44 artefact role) ----
  * The whole TRU-Net forward of network.py:153-171 (R1-R4, TGRU not executed) for N independent frames in ONE launch:
  * x (N, Cin, 257) -> y (N, 8, 257), Cin in {3, 4}.  BatchNorm (eval: running statistics) is folded into the conv in front
- * of it by the exporter; `blob` is the exported weight image (32-row tiles in MFMA fragment order) and h_offsets the 26
+ * of it by the exporter; `blob` is the exported weight image (32-row tiles for the 128-channel encoder layers, 16-row tiles
+ * for the GRU projection and every 64-channel layer, each in MFMA fragment order) and h_offsets the 26
  * element offsets of its sections (first conv | 5 encoder pw | 5 depthwise | GRU projection | W_hh, b_hh | FGRU conv |
  * 6 decoder pw | 5 transposed convs | last transposed conv), as written by tinyrecurrentunet_amd/export.py.  Every
  * workgroup takes one frame at a time through all layers in its own LDS; `scratch` holds the skip tensors of the frames

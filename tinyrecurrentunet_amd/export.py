@@ -3,8 +3,9 @@ a deployable inference artefact, and of ``rt.py:13-27``: load it and run the 1-f
 
 ``fold(net)`` folds every BatchNorm (running statistics, eval semantics of network.py:31,39,51,65,72,...) into the conv
 in front of it and lays the weights out for the single-launch forward kernel ``trunet_stream_fwd`` (stream_fwd.hip):
-32-row tiles in MFMA fragment order (A fragments then 16 bias values per lane), per-tap matrices for the transposed
-convs.  The artefact is ONE flat fp32 tensor + 26 offsets; ``FoldedTRUNet.save`` / ``load`` store it with
+weight tiles in MFMA fragment order -- 32-row tiles (v_mfma_f32_32x32x2_f32: A fragments then 16 bias values per lane) for
+the 128-channel encoder layers, 16-row tiles (v_mfma_f32_16x16x4_f32: A fragments then 4 bias values) for the GRU
+projection, FGRU.conv and every decoder layer -- and per-tap matrices for the transposed convs.  The artefact is ONE flat fp32 tensor + 26 offsets; ``FoldedTRUNet.save`` / ``load`` store it with
 ``torch.save`` and read it back with ``weights_only=True``.  ``FoldedTRUNet.forward(x)`` is the whole network in one
 kernel launch: (N, C_in, 257) -> (N, 8, 257), every frame independent (the reference's forward without TGRU, R4)."""
 import ctypes as C
