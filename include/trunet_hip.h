@@ -310,23 +310,28 @@ int trunet_l1_grad(const float* den, const float* clean, const float* scale, flo
 int trunet_reduce_cols(const float* partials, int nparts, int ncols, float* out, void* stream);
 /* One resolution of MultiResolutionSTFTLoss (stft_loss.py:9-113): win = Hann(win_length) zero-padded to n,
  * frames = 1 + L/hop.  fwd: partials[(b*frames + f)][3] = sum (|Y|-|X|)^2, sum |Y|^2, sum |log|Y| - log|X||
- * with |.| = sqrt(clamp(re^2+im^2, 1e-7)).  bwd (legacy form, float atomics: gx must be zero-filled; the engine uses
- * trunet_stft_loss_bwd_gather below, which has none): adds d loss / d x into gx (B, L) given
- * coef[0] = g_sc*lambda_sc/(nres*sqrt(S1)*sqrt(S2)), coef[1] = g_mag*lambda_mag/(nres*count). */
+ * with |.| = sqrt(clamp(re^2+im^2, 1e-7)). */
 int trunet_stft_loss_fwd(const float* x, const float* y, const float* win, const float* tw, float* partials,
                          int B, int L, int n, int hop, void* stream);
-int trunet_stft_loss_bwd(const float* x, const float* y, const float* win, const float* tw, const float* coef,
-                         float* gx, int B, int L, int n, int hop, void* stream);
-/* trunet_stft_loss_bwd without float atomics: the windowed frame gradients go to `frames` (B, frames, win_length: the
- * window's support, centred in n) and a gather sums them per sample; gx is written (not accumulated), deterministic. */
+/* bwd: d loss / d x -> gx (B, L) given coef[0] = g_sc*lambda_sc/(nres*sqrt(S1)*sqrt(S2)), coef[1] =
+ * g_mag*lambda_mag/(nres*count).  No float atomics: the windowed frame gradients go to `frames` (B, frames, win_length:
+ * the window's support, centred in n) and a gather sums them per sample; gx is written (not accumulated), deterministic. */
 int trunet_stft_loss_bwd_gather(const float* x, const float* y, const float* win, const float* tw, const float* coef,
                                 float* frames, float* gx, int B, int L, int n, int hop, int win_length, void* stream);
 /* stft() of stft_loss.py:9-30: magnitudes sqrt(clamp(re^2+im^2, 1e-7)) of the Hann-windowed, centre/reflect-padded STFT
  * as (B, 1 + L/hop, n/2 + 1); y / ymag may be NULL (one signal), else both signals share one complex FFT. */
 int trunet_stft_mag(const float* x, const float* y, const float* win, const float* tw, float* xmag, float* ymag, int B,
                     int L, int n, int hop, void* stream);
+/* backward of trunet_stft_mag for x (autograd of stft_loss.py:9-30): gmag (B, frames, n/2+1) = cotangent of the
+ * magnitudes -> gx (B, L); frames: scratch (B, frames, win_length); same recompute + gather scheme as above. */
+int trunet_stft_mag_bwd(const float* x, const float* win, const float* tw, const float* gmag, float* frames, float* gx,
+                        int B, int L, int n, int hop, int win_length, void* stream);
 /* PhaseAwareMask.forward (phm.py:31-45 + R5) on interleaved complex64: out = sigmoid(beta(angle m - angle e)) |m| */
 int trunet_phm_fwd(const float* mix_ri, const float* est_ri, float* out, int64_t n, float beta, void* stream);
+/* its backward (autograd of phm.py:31-45): g_out real (n) -> gradients of the two complex inputs in torch's convention
+ * (d/d re + j d/d im, interleaved); either output may be NULL */
+int trunet_phm_bwd(const float* mix_ri, const float* est_ri, const float* g_out, float* g_mix_ri, float* g_est_ri,
+                   int64_t n, float beta, void* stream);
 
 /* ---- eval-mode single-launch forward (rt.py:20-27 protocol, onnx.py:14-44 artefact role) ----
  * The whole TRU-Net forward of network.py:153-171 (R1-R4, TGRU not executed) for N independent frames in ONE launch:

@@ -208,6 +208,73 @@ def gen_sched(ref):
     save("sched", lrs=np.array(lrs, dtype=np.float64))
 
 
+def gen_sched_wrap(ref):
+    """the same class across its wrap-around (two and a bit cycles of 40 steps) and resumed inside either phase"""
+    class _Opt:
+        param_groups = [{"lr": 0.0}]
+    mk = lambda it: ref.sched.LinearWarmupCosineDecay(_Opt(), lr_max=4e-4, n_iter=40, iteration=it, divider=25,  # noqa: E731
+                                                      warmup_proportion=0.25, phase=("linear", "cosine"))
+    s = mk(0)
+    cyc = [s.step() for _ in range(95)]
+    s = mk(4)
+    res_warm = [s.step() for _ in range(50)]
+    s = mk(25)
+    res_decay = [s.step() for _ in range(50)]
+    s = ref.sched.LinearWarmupCosineDecay(_Opt(), lr_max=1e-3, n_iter=30, iteration=0, divider=10, warmup_proportion=0.3,
+                                          phase=("cosine", "linear"))
+    swapped = [s.step() for _ in range(70)]
+    save("sched_wrap", cycles=np.array(cyc), resumed_warm=np.array(res_warm), resumed_decay=np.array(res_decay),
+         swapped=np.array(swapped))
+
+
+def gen_stft_fn(ref):
+    """the stand-alone stft() of stft_loss.py:9-30 with its autograd gradient; one input row is silent over a stretch so
+    that clamp(min=1e-7) is active for whole frames"""
+    x = rnd((2, 2000), 31, 0.1)
+    x[1, 600:1500] = 0.0
+    outs = {"x": x}
+    for n, hop, wl in ((512, 120, 240), (1024, 250, 600)):
+        xx = x.clone().requires_grad_(True)
+        mag = ref.stft_loss.stft(xx, n, hop, wl, torch.hann_window(wl))
+        cot = rnd(tuple(mag.shape), 32 + n)
+        (mag * cot).sum().backward()
+        outs.update({"mag_%d" % n: mag, "cot_%d" % n: cot, "gx_%d" % n: xx.grad})
+    save("stft_fn", **outs)
+
+
+def gen_phm(ref):
+    """PhaseAwareMask.forward of phm.py:31-45, UNMODIFIED.  Its line 41 reads two names, `phase_mix` and `phase_est`,
+    that the function never binds (it binds `phase_mixture` / `phase_estimated`), so as written it raises
+    NameError; Python resolves them as module globals, so binding those two globals to the angles the function itself
+    computes two lines above makes the reference's own code produce the value it evidently means (repair R5)."""
+    rng = np.random.default_rng(77)
+    shape = (257, 21)
+    mix = torch.complex(torch.tensor(rng.standard_normal(shape), dtype=torch.float32),
+                        torch.tensor(rng.standard_normal(shape), dtype=torch.float32))
+    est = torch.complex(torch.tensor(rng.standard_normal(shape), dtype=torch.float32),
+                        torch.tensor(rng.standard_normal(shape), dtype=torch.float32))
+    # edge cases of angle()/abs(): zeros, purely real negative (angle = pi), purely imaginary
+    mix[0, 0] = 0
+    est[0, 1] = 0
+    mix[1, 0] = -1.5
+    est[1, 1] = -0.25
+    mix[2, 0] = 2.0j
+    est[2, 1] = -3.0j
+    outs = {}
+    for beta in (0.5, 2.0):
+        m = mix.clone().requires_grad_(True)
+        e = est.clone().requires_grad_(True)
+        ref.phm.phase_mix = torch.angle(m)
+        ref.phm.phase_est = torch.angle(e)
+        out = ref.phm.PhaseAwareMask(beta).forward(m, e)
+        cot = torch.tensor(np.random.default_rng(78).standard_normal(shape), dtype=torch.float32)
+        (out * cot).sum().backward()
+        tag = "b%02d" % int(beta * 10)
+        outs.update({"out_" + tag: out, "gmix_" + tag: torch.view_as_real(m.grad), "gest_" + tag: torch.view_as_real(e.grad)})
+        del ref.phm.phase_mix, ref.phm.phase_est
+    save("phm", mix=torch.view_as_real(mix), est=torch.view_as_real(est), cot=cot, **outs)
+
+
 def gen_config():
     """the values of config/tiny.json's sections that reach the hot-path modules as **kwargs (train.py:180-192): data
     for the drop-in tests (constructor / loss_fn / loader keyword names and values), no code"""
@@ -227,8 +294,16 @@ if __name__ == "__main__":
         gen_config()
         sys.exit(0)
     ref = load_reference()
-    if len(sys.argv) > 1:               # python tests/golden/make_golden.py block:gru_uni ...  (add single fixtures)
-        gen_blocks(ref, only=[a.split(":", 1)[1] for a in sys.argv[1:] if a.startswith("block:")])
+    if len(sys.argv) > 1:               # python tests/golden/make_golden.py block:gru_uni phm ...  (add single fixtures)
+        only = [a.split(":", 1)[1] for a in sys.argv[1:] if a.startswith("block:")]
+        if only:
+            gen_blocks(ref, only=only)
+        if "phm" in sys.argv[1:]:
+            gen_phm(ref)
+        if "sched_wrap" in sys.argv[1:]:
+            gen_sched_wrap(ref)
+        if "stft_fn" in sys.argv[1:]:
+            gen_stft_fn(ref)
         sys.exit(0)
     gen_config()
     gen_blocks(ref)
@@ -236,3 +311,6 @@ if __name__ == "__main__":
     gen_stft_loss(ref)
     gen_features(ref)
     gen_sched(ref)
+    gen_sched_wrap(ref)
+    gen_phm(ref)
+    gen_stft_fn(ref)

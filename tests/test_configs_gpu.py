@@ -181,6 +181,37 @@ def test_folded_single_launch_forward_matches_reference_golden(golden, cin, tmp_
         assert float((y2 - y - 1.0).abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_folded_cache_follows_the_products_own_training_steps(precision):
+    """train -> eval -> more training steps -> eval: FusedAdamW and the BatchNorm running statistics write through raw
+    device pointers (tensor version counters do not move), so the cached fold must be invalidated by the product's own
+    mutation epoch.  The folded eval forward has to equal the layer-by-layer eval forward after every round."""
+    from tinyrecurrentunet_amd import optim
+    _, net = _pair(4, seed=3)
+    net.set_precision(precision)
+    opt = optim.FusedAdamW(net.parameters(), lr=5e-3)
+    gen = torch.Generator().manual_seed(11)
+    xt = (torch.randn(96, 4, 257, generator=gen) * 0.7).cuda()
+    xe = (torch.randn(7, 4, 257, generator=gen) * 0.7).cuda()
+    prev = None
+    for rnd in range(3):
+        net.train()
+        for _ in range(2):
+            opt.zero_grad()
+            net(xt).square().mean().backward()
+            opt.step()
+        net.eval()
+        with torch.no_grad():
+            y = net(xe)                                  # folded single-launch path
+            net.fold_eval = False
+            y_layers = net(xe)                           # layer-by-layer kernels, always from the live tensors
+            net.fold_eval = True
+        assert _rel(y, y_layers) < 1e-5, (rnd, _rel(y, y_layers))
+        if prev is not None:
+            assert _rel(y, prev) > 1e-3                  # the weights and statistics really moved in between
+        prev = y
+
+
 @pytest.mark.parametrize("N", [1, 255, 1024, 2500])
 def test_folded_forward_vs_oracle_f64(N):
     """ragged / multi-frame-per-workgroup counts (one workgroup takes frames n, n + grid, ...): 1e-4 vs the fp64 oracle"""

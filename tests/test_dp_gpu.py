@@ -95,3 +95,28 @@ def test_bench_two_ranks_complete_without_deadlock(dtype):
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 8 and res["value"] > 0
     assert res["roofline"] is not None and res["cpu_baseline"] is None and res["dtype"] == dtype
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_bare_bench_gpus_2_starts_its_own_ranks(dtype):
+    """`python bench.py --gpus 2` with NO launcher (how the driver calls the benchmark): the parent starts the two ranks
+    itself (reference: distributed.py:150-176), relays one JSON line and reports what torch.distributed saw.  Both ranks
+    share cuda:0 over gloo here (one GPU per box); on a node the same code path runs RCCL with one GPU per rank."""
+    import json
+    import subprocess
+    env = dict(os.environ, TRUNET_BENCH_ONE_DEVICE="1", TRUNET_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+           "--seconds", "1", "--dtype", dtype]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 8 and res["value"] > 0 and res["dtype"] == dtype
+    d = res["dist"]
+    assert d["world_size_seen"] == 2 and d["dist_backend"] == "gloo" and d["self_spawned"] is True
+    assert d["ms_per_step_rank_min"] <= d["ms_per_step_rank_max"] and len(d["device_of_rank"]) == 2
+    assert d["allreduce_ms"] is not None and d["allreduce_ms"] > 0 and d["allreduce_in_place"] is True
+    assert d["allreduce_bytes"] == 4 * 298592

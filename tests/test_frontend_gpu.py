@@ -82,6 +82,61 @@ def test_phm_vs_oracle():
     assert _rel(out, fr.phase_aware_mask(m, e, 0.5)) < 1e-5
 
 
+def test_phm_matches_reference_golden(golden):
+    """a10 pinned: trunet_phm_fwd / trunet_phm_bwd vs values produced by the reference's own PhaseAwareMask.forward
+    (tests/golden/make_golden.py gen_phm), incl. zeros / negative-real / purely imaginary inputs"""
+    from tinyrecurrentunet_amd import phm
+    g = golden("phm")
+    cot = torch.tensor(g["cot"]).cuda()
+    for tag, beta in (("b05", 0.5), ("b20", 2.0)):
+        m = torch.view_as_complex(torch.tensor(g["mix"])).cuda().requires_grad_(True)
+        e = torch.view_as_complex(torch.tensor(g["est"])).cuda().requires_grad_(True)
+        out = phm.PhaseAwareMask(beta)(m, e)
+        ref = torch.tensor(g["out_" + tag])
+        assert float((out.cpu() - ref).abs().max()) < 1e-5 * float(ref.abs().max())
+        (out * cot).sum().backward()
+        for got, key in ((m.grad, "gmix_" + tag), (e.grad, "gest_" + tag)):
+            r = torch.tensor(g[key])
+            assert float((torch.view_as_real(got).cpu() - r).abs().max()) < 2e-5 * float(r.abs().max()), key
+    # only one input needs a gradient; a real-valued input gets a real gradient
+    m = torch.view_as_complex(torch.tensor(g["mix"])).cuda()
+    e = torch.view_as_complex(torch.tensor(g["est"])).cuda().requires_grad_(True)
+    phm.PhaseAwareMask(0.5)(m, e).sum().backward()
+    assert e.grad is not None and e.grad.dtype == torch.complex64
+
+
+def test_stft_fn_and_gradient_match_reference_golden(golden):
+    """a12: the stand-alone stft() is differentiable like stft_loss.py:9-30; magnitudes and d/dx vs the reference's"""
+    from tinyrecurrentunet_amd import stft_loss as sl
+    g = golden("stft_fn")
+    for n, hop, wl in ((512, 120, 240), (1024, 250, 600)):
+        x = torch.tensor(g["x"]).cuda().requires_grad_(True)
+        mag = sl.stft(x, n, hop, wl, torch.hann_window(wl).cuda())
+        ref = torch.tensor(g["mag_%d" % n])
+        assert mag.shape == ref.shape and mag.requires_grad
+        assert float((mag.cpu() - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+        (mag * torch.tensor(g["cot_%d" % n]).cuda()).sum().backward()
+        r = torch.tensor(g["gx_%d" % n])
+        assert float((x.grad.cpu() - r).abs().max()) < 1e-4 * float(r.abs().max())
+
+
+def test_stft_gradient_vs_oracle_autograd_2048():
+    """the 2048-point resolution and a longer signal against torch.autograd on the oracle (fp64)"""
+    from oracle import stft_loss_ref as slr
+    from tinyrecurrentunet_amd import stft_loss as sl
+    rng = np.random.default_rng(5)
+    x = torch.tensor(rng.standard_normal((3, 9000)) * 0.1, dtype=torch.float32)
+    x64 = x.double().requires_grad_(True)
+    m64 = slr.stft_mag(x64, 2048, 240, 1200, torch.hann_window(1200, dtype=torch.float64))
+    cot = torch.tensor(rng.standard_normal(tuple(m64.shape)))
+    (m64 * cot).sum().backward()
+    xg = x.cuda().requires_grad_(True)
+    mg = sl.stft(xg, 2048, 240, 1200, torch.hann_window(1200).cuda())
+    assert _rel(mg, m64) < 1e-4
+    (mg * cot.float().cuda()).sum().backward()
+    assert _rel(xg.grad, x64.grad) < 1e-4
+
+
 @pytest.mark.parametrize("B,L", [(2, 4096), (3, 16000)])
 def test_denoise_and_grad_vs_oracle(B, L):
     """mask + iSTFT + L1 stage (R7), forward and backward, vs the oracle in fp64."""

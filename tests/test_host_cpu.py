@@ -457,3 +457,25 @@ def test_checkpoint_round_trip_with_reference_layout(tmp_path):
     assert W.checksum(back) == W.checksum(ref)
     # the use_tgru extension does not change the parameter set
     assert list(hn.TRUNet(input_size=4, use_tgru=True).state_dict()) == list(sd)
+
+
+def test_bare_bench_launcher_fails_loudly_when_a_rank_dies():
+    """`python bench.py --gpus 2` is its own launcher (reference: distributed.py:150-176).  Without a GPU no rank can
+    run, so what is checked here is the launcher: it starts the ranks without importing the product or touching the
+    GPU itself, a rank that dies takes the job down (the other rank is terminated, not left waiting at the rendezvous),
+    and the parent's exit code is non-zero with no JSON line on stdout."""
+    import subprocess
+    env = dict(os.environ, TRUNET_BENCH_FAIL_RANK="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert "stopping the other ranks" in out.stderr or "exited with code" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_use_tgru_bf16_is_refused_at_construction():
+    from tinyrecurrentunet_amd import _lib, network as hn
+    with pytest.raises(_lib.TrunetHipError):
+        hn.TRUNet(input_size=4, use_tgru=True, precision="bf16")

@@ -122,3 +122,49 @@ def test_sched_matches_reference(golden):
         assert abs(loss_ref.lr_schedule(s, 4e-4, 1000, 25, 0.05) - lrs[s - 1]) < 1e-15 + 1e-12 * lrs[s - 1]
     for s, v in ((1, 2.368e-05), (50, 4e-4), (51, 3.999989e-4), (525, 2.000008e-4), (1000, 1.6e-9)):
         assert abs(lrs[s - 1] - v) < 2e-10
+
+
+def test_phm_matches_reference(golden):
+    """a10: the oracle's mask against values the REFERENCE's own unmodified PhaseAwareMask.forward produced (its two
+    unbound names bound as module globals by make_golden.gen_phm), forward and autograd gradients, incl. the
+    angle()/abs() edge cases (zeros, negative real, purely imaginary inputs)"""
+    g = golden("phm")
+    for tag, beta in (("b05", 0.5), ("b20", 2.0)):
+        m = torch.view_as_complex(T(g["mix"])).clone().requires_grad_(True)
+        e = torch.view_as_complex(T(g["est"])).clone().requires_grad_(True)
+        out = fr.phase_aware_mask(m, e, beta=beta)
+        close(out, g["out_" + tag], rtol=1e-6, atol=1e-7)
+        (out * T(g["cot"])).sum().backward()
+        close(torch.view_as_real(m.grad), g["gmix_" + tag], rtol=1e-5, atol=1e-6)
+        close(torch.view_as_real(e.grad), g["gest_" + tag], rtol=1e-5, atol=1e-6)
+
+
+def test_stft_fn_matches_reference(golden):
+    """a12: stft() magnitudes and their autograd gradient vs the reference's stft_loss.stft"""
+    g = golden("stft_fn")
+    for n, hop, wl in ((512, 120, 240), (1024, 250, 600)):
+        x = T(g["x"]).clone().requires_grad_(True)
+        mag = sl.stft_mag(x, n, hop, wl, torch.hann_window(wl))
+        close(mag, g["mag_%d" % n], rtol=1e-5, atol=1e-6)
+        (mag * T(g["cot_%d" % n])).sum().backward()
+        close(x.grad, g["gx_%d" % n], rtol=1e-4, atol=1e-5)
+
+
+def test_sched_wrap_matches_reference(golden):
+    """the product's closed-form LinearWarmupCosineDecay across wrap-arounds, resumed in either phase, and with the two
+    curve shapes swapped, vs the reference class (util.py:110-156)"""
+    from tinyrecurrentunet_amd import util
+    g = golden("sched_wrap")
+
+    class Opt:
+        param_groups = [{"lr": 0.0}]
+
+    def run(n, **kw):
+        s = util.LinearWarmupCosineDecay(Opt(), **kw)
+        return np.array([s.step() for _ in range(n)])
+    base = dict(lr_max=4e-4, n_iter=40, divider=25, warmup_proportion=0.25, phase=("linear", "cosine"))
+    np.testing.assert_allclose(run(95, iteration=0, **base), g["cycles"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(run(50, iteration=4, **base), g["resumed_warm"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(run(50, iteration=25, **base), g["resumed_decay"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(run(70, lr_max=1e-3, n_iter=30, iteration=0, divider=10, warmup_proportion=0.3,
+                                   phase=("cosine", "linear")), g["swapped"], rtol=1e-12, atol=0)

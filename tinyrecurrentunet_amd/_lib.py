@@ -171,10 +171,11 @@ def _declare(L):
         "trunet_l1_grad": [p, p, p, p, i64, p],
         "trunet_reduce_cols": [p, i, i, p, p],
         "trunet_stft_loss_fwd": [p, p, p, p, p, i, i, i, i, p],
-        "trunet_stft_loss_bwd": [p, p, p, p, p, p, i, i, i, i, p],
         "trunet_stft_mag": [p, p, p, p, p, p, i, i, i, i, p],
         "trunet_stft_loss_bwd_gather": [p, p, p, p, p, p, p, i, i, i, i, i, p],
+        "trunet_stft_mag_bwd": [p, p, p, p, p, p, i, i, i, i, i, p],
         "trunet_phm_fwd": [p, p, p, i64, f, p],
+        "trunet_phm_bwd": [p, p, p, p, p, i64, f, p],
         "trunet_augment_mix": [p, p, p, p, p, i, i, p],
         "trunet_stream_fwd_grid": [i],
         "trunet_stream_fwd_scratch_floats": [i],
@@ -250,6 +251,20 @@ def make_seg(src0, nchan, L, pos_mul=1, pos_off=0, pos_div=1, woff=0, mode=PRO_N
 # between parameters are zero); the gradient all-reduce and FusedAdamW look the buffer up here by storage address and
 # work on it in place instead of packing the ~100 gradients again.
 _FLAT = {}          # storage address -> (flat tensor, layout, total); the newest few are kept alive (1.2 MB each)
+
+
+# Weights and BatchNorm buffers are also written through raw device pointers (FusedAdamW, bn_finalize_fwd), which does
+# not move torch's tensor version counters: everything that caches a function of them (TRUNet.folded) keys on this
+# epoch as well, and every such writer bumps it.
+_MUTATION_EPOCH = [0]
+
+
+def mutation_epoch():
+    return _MUTATION_EPOCH[0]
+
+
+def bump_mutation_epoch():
+    _MUTATION_EPOCH[0] += 1
 
 
 def register_flat_grad(flat, layout, total):

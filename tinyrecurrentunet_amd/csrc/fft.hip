@@ -426,14 +426,19 @@ __global__ __launch_bounds__(1024) void reduce_cols_kernel(const float* __restri
     }
 }
 
-// backward: coef[0] = d loss / d(sum (ym-xm)^2 -> sc) prefactor, see host; per bin
+// backward of one resolution.  MAG == false (the losses): per bin
 //   g_xm = coef[0] * (xm - ym) + coef[1] * sign(log xm - log ym) / xm
-// with coef[0] = g_sc * lam_sc / (nres * sqrt(S1) * sqrt(S2)), coef[1] = g_mag * lam_mag / (nres * count)
-__global__ __launch_bounds__(256) void stft_loss_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                            const float* __restrict__ win, const cpx* __restrict__ tw,
-                                                            const float* __restrict__ coef, float* __restrict__ gx, int L,
-                                                            int n, int logn, int hop, float* __restrict__ fr, int wl,
-                                                            int left) {
+// with coef[0] = g_sc * lam_sc / (nres * sqrt(S1) * sqrt(S2)), coef[1] = g_mag * lam_mag / (nres * count);
+// MAG == true (the stand-alone stft() of stft_loss.py:9-30): g_xm = gmag[b][f][k], the cotangent of the magnitudes.
+// Either way the frame FFT is recomputed, the gradient half spectrum g_xm * X / xm (zero where clamp(min=1e-7) is
+// active) goes through the inverse FFT, and the windowed real part over the window's support is written to `fr`
+// (B, frames, wl); ola_gather_kernel sums the frames per sample -- no float atomics.
+template <bool MAG>
+__global__ __launch_bounds__(256) void stft_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                       const float* __restrict__ win, const cpx* __restrict__ tw,
+                                                       const float* __restrict__ coef, const float* __restrict__ gmag,
+                                                       int L, int n, int logn, int hop, float* __restrict__ fr, int wl,
+                                                       int left) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
     cpx* sa = (cpx*)smraw;
     cpx* sb = sa + n;
@@ -441,15 +446,16 @@ __global__ __launch_bounds__(256) void stft_loss_bwd_kernel(const float* __restr
     for (int i = threadIdx.x; i < n / 2; i += 256) stw[i] = tw[i];
     const int f = blockIdx.x, b = blockIdx.y;
     const float* xb = x + (size_t)b * L;
-    const float* yb = y + (size_t)b * L;
+    const float* yb = MAG ? xb : y + (size_t)b * L;
     for (int i = threadIdx.x; i < n; i += 256) {
         const int j = reflect_idx(f * hop + i - n / 2, L);
         const float w = win[i];
-        sa[i] = make_float2(w * xb[j], w * yb[j]);
+        sa[i] = make_float2(w * xb[j], MAG ? 0.f : w * yb[j]);
     }
     cpx* Z = fft_lds(sa, sb, n, logn, stw, false);
     cpx* other = (Z == sa) ? sb : sa;
-    const float c_sc = coef[0], c_mag = coef[1];
+    const float c_sc = MAG ? 0.f : coef[0], c_mag = MAG ? 0.f : coef[1];
+    const float* gm_row = MAG ? gmag + ((size_t)b * gridDim.x + f) * (n / 2 + 1) : nullptr;
     // build the half spectrum of gradients in `other` (upper half zero), then inverse FFT, real part
     for (int k = threadIdx.x; k < n; k += 256) {
         cpx G = make_float2(0.f, 0.f);
@@ -459,34 +465,27 @@ __global__ __launch_bounds__(256) void stft_loss_bwd_kernel(const float* __restr
             const float px = X.x * X.x + X.y * X.y;
             if (px > 1e-7f) {   // clamp(min=1e-7) passes no gradient below the floor
                 const float xm = sqrtf(px);
-                const float ym = sqrtf(fmaxf(Y.x * Y.x + Y.y * Y.y, 1e-7f));
-                const float dl = logf(xm) - logf(ym);
-                const float sg = (dl > 0.f) ? 1.f : ((dl < 0.f) ? -1.f : 0.f);
-                const float gm = c_sc * (xm - ym) + c_mag * sg / xm;
+                float gm;
+                if (MAG) {
+                    gm = gm_row[k];
+                } else {
+                    const float ym = sqrtf(fmaxf(Y.x * Y.x + Y.y * Y.y, 1e-7f));
+                    const float dl = logf(xm) - logf(ym);
+                    const float sg = (dl > 0.f) ? 1.f : ((dl < 0.f) ? -1.f : 0.f);
+                    gm = c_sc * (xm - ym) + c_mag * sg / xm;
+                }
                 G = make_float2(gm * X.x / xm, gm * X.y / xm);
             }
         }
         other[k] = G;
     }
     const cpx* g = fft_lds(other, Z, n, logn, stw, true);
-    if (fr) {
-        // windowed time-domain gradient of this frame, the window's support only: summed per sample by ola_gather_kernel
-        float* fo = fr + ((size_t)b * gridDim.x + f) * wl;
-        for (int i = threadIdx.x; i < wl; i += 256) fo[i] = win[left + i] * g[left + i].x;
-        return;
-    }
-    float* gb = gx + (size_t)b * L;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const float w = win[i];
-        if (w != 0.f) {
-            const int j = reflect_idx(f * hop + i - n / 2, L);
-            atomicAdd(gb + j, w * g[i].x);
-        }
-    }
+    float* fo = fr + ((size_t)b * gridDim.x + f) * wl;
+    for (int i = threadIdx.x; i < wl; i += 256) fo[i] = win[left + i] * g[left + i].x;
 }
 
 // gx[b][j] = sum over the frames (and, near the ends, the reflected positions) whose window support covers sample j:
-// the overlap-add of stft_loss_bwd_kernel's frames as a gather -- no float atomics, deterministic.
+// the overlap-add of stft_bwd_kernel's frames as a gather -- no float atomics, deterministic.
 __global__ __launch_bounds__(256) void ola_gather_kernel(const float* __restrict__ fr, float* __restrict__ gx, int L, int n,
                                                          int hop, int nframes, int wl, int left) {
     const int b = blockIdx.y;
@@ -520,6 +519,32 @@ __global__ void phm_kernel(const float2* __restrict__ m, const float2* __restric
     const float2 a = m[i], b = e[i];
     const float d = atan2f(a.y, a.x) - atan2f(b.y, b.x);
     out[i] = sqrtf(a.x * a.x + a.y * a.y) / (1.f + expf(-beta * d));
+}
+
+// backward of phm_kernel: out = s |m|, s = sigmoid(beta (angle m - angle e)).  Gradients in torch's convention for a real
+// loss and complex inputs (d/d re + j d/d im); angle() and abs() pass no gradient at 0, like torch.
+__global__ void phm_bwd_kernel(const float2* __restrict__ m, const float2* __restrict__ e, const float* __restrict__ gout,
+                               float2* __restrict__ gm, float2* __restrict__ ge, int64_t n, float beta) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float2 a = m[i], b = e[i];
+    const float g = gout[i];
+    const float d = atan2f(a.y, a.x) - atan2f(b.y, b.x);
+    const float sg = 1.f / (1.f + expf(-beta * d));
+    const float pa = a.x * a.x + a.y * a.y, pb = b.x * b.x + b.y * b.y;
+    const float mag = sqrtf(pa);
+    const float gth = g * mag * sg * (1.f - sg) * beta;            // d loss / d (angle m - angle e)
+    float2 ra = make_float2(0.f, 0.f), rb = make_float2(0.f, 0.f);
+    if (pa > 0.f) {
+        ra.x = gth * (-a.y / pa) + g * sg * a.x / mag;
+        ra.y = gth * (a.x / pa) + g * sg * a.y / mag;
+    }
+    if (pb > 0.f) {
+        rb.x = -gth * (-b.y / pb);
+        rb.y = -gth * (b.x / pb);
+    }
+    if (gm) gm[i] = ra;
+    if (ge) ge[i] = rb;
 }
 
 }  // namespace
@@ -593,16 +618,6 @@ extern "C" int trunet_stft_mag(const float* x, const float* y, const float* win,
     return trunet_launch_status();
 }
 
-extern "C" int trunet_stft_loss_bwd(const float* x, const float* y, const float* win, const float* tw, const float* coef,
-                                    float* gx, int B, int L, int n, int hop, void* stream) {
-    const int logn = ilog2(n);
-    if (!x || !y || !win || !tw || !coef || !gx || B <= 0 || logn < 3 || n > 4096 || hop <= 0 || L <= n / 2) return TRUNET_EINVAL;
-    const int nframes = 1 + L / hop;
-    hipLaunchKernelGGL(stft_loss_bwd_kernel, dim3(nframes, B), dim3(256), (2 * n + n / 2) * sizeof(cpx), ST, x, y, win, (const cpx*)tw,
-                       coef, gx, L, n, logn, hop, (float*)nullptr, 0, 0);
-    return trunet_launch_status();
-}
-
 extern "C" int trunet_stft_loss_bwd_gather(const float* x, const float* y, const float* win, const float* tw,
                                            const float* coef, float* frames, float* gx, int B, int L, int n, int hop,
                                            int win_length, void* stream) {
@@ -612,10 +627,33 @@ extern "C" int trunet_stft_loss_bwd_gather(const float* x, const float* y, const
         return TRUNET_EINVAL;
     const int nframes = 1 + L / hop;
     const int left = (n - win_length) / 2;
-    hipLaunchKernelGGL(stft_loss_bwd_kernel, dim3(nframes, B), dim3(256), (2 * n + n / 2) * sizeof(cpx), ST, x, y, win, (const cpx*)tw,
-                       coef, gx, L, n, logn, hop, frames, win_length, left);
+    hipLaunchKernelGGL(stft_bwd_kernel<false>, dim3(nframes, B), dim3(256), (2 * n + n / 2) * sizeof(cpx), ST, x, y, win,
+                       (const cpx*)tw, coef, (const float*)nullptr, L, n, logn, hop, frames, win_length, left);
     hipLaunchKernelGGL(ola_gather_kernel, dim3((L + 255) / 256, B), dim3(256), 0, ST, frames, gx, L, n, hop, nframes,
                        win_length, left);
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_stft_mag_bwd(const float* x, const float* win, const float* tw, const float* gmag, float* frames,
+                                   float* gx, int B, int L, int n, int hop, int win_length, void* stream) {
+    const int logn = ilog2(n);
+    if (!x || !win || !tw || !gmag || !frames || !gx || B <= 0 || logn < 3 || n > 4096 || hop <= 0 || L <= n / 2 ||
+        win_length <= 0 || win_length > n)
+        return TRUNET_EINVAL;
+    const int nframes = 1 + L / hop;
+    const int left = (n - win_length) / 2;
+    hipLaunchKernelGGL(stft_bwd_kernel<true>, dim3(nframes, B), dim3(256), (2 * n + n / 2) * sizeof(cpx), ST, x, x, win,
+                       (const cpx*)tw, (const float*)nullptr, gmag, L, n, logn, hop, frames, win_length, left);
+    hipLaunchKernelGGL(ola_gather_kernel, dim3((L + 255) / 256, B), dim3(256), 0, ST, frames, gx, L, n, hop, nframes,
+                       win_length, left);
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_phm_bwd(const float* mix_ri, const float* est_ri, const float* g_out, float* g_mix_ri, float* g_est_ri,
+                              int64_t n, float beta, void* stream) {
+    if (!mix_ri || !est_ri || !g_out || (!g_mix_ri && !g_est_ri) || n <= 0) return TRUNET_EINVAL;
+    hipLaunchKernelGGL(phm_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ST, (const float2*)mix_ri,
+                       (const float2*)est_ri, g_out, (float2*)g_mix_ri, (float2*)g_est_ri, n, beta);
     return trunet_launch_status();
 }
 

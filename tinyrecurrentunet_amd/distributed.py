@@ -57,6 +57,18 @@ class FlatGradAllReduce:
         self.flat = None
         self.params = None
         self.in_place = None      # True when the last reduce ran on the engine's flat gradient tensor itself
+        self.timing = None        # a list here makes reduce() append (start, end) events around the exchange step
+
+    @staticmethod
+    def _mean_all_reduce(flat):
+        """SUM over ranks and / world (distributed.py:127-134).  RCCL divides inside the collective (ncclAvg: the
+        operands are pre-multiplied by 1/world, exact for the power-of-two rank counts of one node), so the exchange
+        step is ONE launch; gloo has no AVG, there the division is a second pass."""
+        if dist.get_backend() == "nccl":
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            flat /= dist.get_world_size()
 
     @staticmethod
     def _engine_flat(params):
@@ -77,10 +89,19 @@ class FlatGradAllReduce:
         params = [p for p in self.module.parameters() if p.requires_grad and p.grad is not None]
         if not params:
             return
+        if self.timing is not None and params[0].is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+            self._reduce(params)
+            ev[1].record()
+            self.timing.append(ev)
+        else:
+            self._reduce(params)
+
+    def _reduce(self, params):
         flat = self._engine_flat(params)
         if flat is not None:               # every p.grad is a view of this tensor: reduce it where it lies
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-            flat /= dist.get_world_size()
+            self._mean_all_reduce(flat)
             self.in_place = True
             return
         self.in_place = False
@@ -96,8 +117,7 @@ class FlatGradAllReduce:
                 off += p.numel()
         grads = [p.grad for p in params]
         torch._foreach_copy_(self.views, grads)
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        self.flat /= dist.get_world_size()
+        self._mean_all_reduce(self.flat)
         torch._foreach_copy_(grads, self.views)
 
 

@@ -370,6 +370,7 @@ class TRUNetEngine:
         lib = L.lib()
         if training:
             part = w.flat("partials", nparts * C * 2)
+            L.bump_mutation_epoch()     # running statistics are written through raw pointers
             rm = module.running_mean if module.track_running_stats else None
             rv = module.running_var if module.track_running_stats else None
             mom = BN_MOM if module.momentum is None else module.momentum
@@ -428,6 +429,7 @@ class TRUNetEngine:
         st = w.bn(name, C)
         st.module, st.count = bn, float(N * Lo)
         if training:
+            L.bump_mutation_epoch()     # running statistics are written through raw pointers
             rm = bn.running_mean if bn.track_running_stats else None
             rv = bn.running_var if bn.track_running_stats else None
             mom = BN_MOM if bn.momentum is None else bn.momentum

@@ -121,7 +121,9 @@ class TRUNetEngineBF16(TRUNetEngine):
             if self._pkoff + n > PACK_POOL_ELEMS:        # pool exhausted (many shapes): start over, everything repacks
                 plan.clear()
                 self._pkoff = 0
-            e = dict(ptr=self._pkbuf.data_ptr() + 2 * self._pkoff, W=W.data_ptr(), M=M, ldw_m=ldw_m, ldw_c=ldw_c,
+            # Wt keeps the source storage alive while the plan can still launch a batched read of its address (the
+            # optimizer re-points p.data at its first step; the entry of the old storage ages out one epoch later)
+            e = dict(ptr=self._pkbuf.data_ptr() + 2 * self._pkoff, W=W.data_ptr(), Wt=W, M=M, ldw_m=ldw_m, ldw_c=ldw_c,
                      w_m_off=w_m_off, nchan=list(nchan), woff=list(woff), nks=nks, epoch=-1, used=self._pkepoch, elems=n)
             self._pkoff += (n + 63) // 64 * 64
             plan[key] = e
@@ -140,7 +142,7 @@ class TRUNetEngineBF16(TRUNetEngine):
             return
         self._pkepoch += 1
         plan = self._pk
-        stale = [k for k, e in plan.items() if e["used"] < self._pkepoch - 2]      # shapes / storages no longer in use
+        stale = [k for k, e in plan.items() if e["used"] < self._pkepoch - 1]      # not used by the previous forward
         for k in stale:
             del plan[k]
             self._pkdirty = True
@@ -291,6 +293,7 @@ class TRUNetEngineBF16(TRUNetEngine):
         st = w.bn(name, Cn)
         st.module, st.count = bn, float(N * Lo)
         if training:
+            L.bump_mutation_epoch()     # running statistics are written through raw pointers
             rm = bn.running_mean if bn.track_running_stats else None
             rv = bn.running_var if bn.track_running_stats else None
             mom = BN_MOM if bn.momentum is None else bn.momentum

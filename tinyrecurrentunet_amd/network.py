@@ -189,11 +189,11 @@ class TRUNet(nn.Module):
         super().__init__()
         # precision (extension; BASELINE.json configs[2]): "bf16" stores activations and their gradients as bf16 and
         # multiplies on the bf16 MFMA (engine_bf16.py); parameters, BatchNorm statistics, gradients of parameters stay fp32
-        self.precision = "fp32"
-        self.set_precision(precision)
         # use_tgru (extension, default = the reference as written, R4): run the TGRU block over time between FGRU and
         # the decoder as drawn in docs/net.jpg; forward then needs frames_per_seq = T (N = B*T frames)
         self.use_tgru = bool(use_tgru)
+        self.precision = "fp32"
+        self.set_precision(precision)      # after use_tgru: the combination (use_tgru, "bf16") is refused here
         self.encoder = nn.ModuleList([
             StandardConv1d(input_size, 64, 5, 2),
             DepthwiseSeparableConv1d(64, 128, 3, 1),
@@ -223,6 +223,11 @@ class TRUNet(nn.Module):
             object.__setattr__(self, "_engine", None)
         self.precision = precision
         return self
+
+    def train(self, mode=True):
+        if mode:
+            object.__setattr__(self, "_folded_cache", None)      # training moves weights and BatchNorm statistics
+        return super().train(mode)
 
     def _make_engine(self):
         if self.precision == "bf16":
@@ -281,7 +286,10 @@ class TRUNet(nn.Module):
         buffer has been modified since (tensor version counters)."""
         from .export import FoldedTRUNet
         ts = [t for n, t in self.state_dict(keep_vars=True).items() if not n.startswith("TGRU.")]
-        key = (tuple(t._version for t in ts), tuple(t.data_ptr() for t in ts[:2]), str(ts[0].device))
+        # version counters catch torch-side writes (load_state_dict, in-place ops); the mutation epoch catches the
+        # product's own raw-pointer writers (FusedAdamW.step, the BatchNorm running statistics of a training forward)
+        key = (tuple(t._version for t in ts), tuple(t.data_ptr() for t in ts[:2]), str(ts[0].device),
+               _lib.mutation_epoch())
         cached = self.__dict__.get("_folded_cache")
         if cached is None or cached[0] != key:
             cached = (key, FoldedTRUNet.from_module(self))

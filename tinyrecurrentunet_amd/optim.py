@@ -90,6 +90,7 @@ class FusedAdamW:
             return None
         g = self.param_groups[0]
         lib = L.lib()
+        L.bump_mutation_epoch()            # the update goes through raw pointers: tensor version counters do not move
         eng = self._engine_layout(active) if active[0].is_cuda else None
         if eng is not None:
             gflat, offs, total = eng

@@ -18,28 +18,51 @@ def _padded_window(window, n):
     return w
 
 
+class _STFTMagFn(torch.autograd.Function):
+    """x (B, L) -> magnitudes (B, frames, bins); backward recomputes the frame FFT (trunet_stft_mag_bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, win, n, hop, wl):
+        x = x.contiguous().float()
+        B, Ln = x.shape
+        tw = L.twiddles(n, x.device)
+        out = torch.empty((B, 1 + Ln // hop, n // 2 + 1), device=x.device, dtype=torch.float32)
+        check(L.lib().trunet_stft_mag(ptr(x), None, ptr(win), ptr(tw), ptr(out), None, B, Ln, n, hop, L.stream()),
+              "stft_mag")
+        ctx.save_for_backward(x, win, tw)
+        ctx.n, ctx.hop, ctx.wl = n, hop, wl
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, win, tw = ctx.saved_tensors
+        B, Ln = x.shape
+        g = g.contiguous().float()
+        frames = torch.empty((B, 1 + Ln // ctx.hop, ctx.wl), device=x.device, dtype=torch.float32)
+        gx = torch.empty_like(x)
+        check(L.lib().trunet_stft_mag_bwd(ptr(x), ptr(win), ptr(tw), ptr(g), ptr(frames), ptr(gx), B, Ln, ctx.n, ctx.hop,
+                                          ctx.wl, L.stream()), "stft_mag_bwd")
+        return gx, None, None, None, None
+
+
 def stft(x, fft_size, hop_size, win_length, window):
-    """stft_loss.py:9-30: (B, L) -> magnitude spectrogram (B, frames, fft_size // 2 + 1) = sqrt(clamp(re^2 + im^2, 1e-7)).
-    Forward only: the training losses never materialise magnitudes (they use the fused three-sums kernel and
-    recompute the frame FFT in backward); this is the reference's stand-alone helper on the same LDS FFT."""
+    """stft_loss.py:9-30: (B, L) -> magnitude spectrogram (B, frames, fft_size // 2 + 1) = sqrt(clamp(re^2 + im^2, 1e-7)),
+    differentiable with respect to x like the reference's (an ordinary autograd function there).  The training losses
+    below never materialise magnitudes (fused three-sums kernel); this is the reference's stand-alone helper on the
+    same LDS FFT."""
     if not x.is_cuda:
         raise L.TrunetHipError("tinyrecurrentunet_amd.stft_loss runs on MI355X only")
-    if x.requires_grad and torch.is_grad_enabled():
-        raise L.TrunetHipError("stft() is forward-only; differentiate through STFTLoss / MultiResolutionSTFTLoss")
-    x = x.detach().contiguous().float()
-    B, Ln = x.shape
+    if x.dim() != 2:
+        raise ValueError("stft expects (B, L), got %s" % (tuple(x.shape),))
     win = _padded_window(window.to(x.device), fft_size)
-    out = torch.empty((B, 1 + Ln // hop_size, fft_size // 2 + 1), device=x.device, dtype=torch.float32)
-    check(L.lib().trunet_stft_mag(ptr(x), None, ptr(win), ptr(L.twiddles(fft_size, x.device)), ptr(out), None, B, Ln,
-                                  fft_size, hop_size, L.stream()), "stft_mag")
-    return out
+    return _STFTMagFn.apply(x, win, fft_size, hop_size, win_length)
 
 
 class _STFTLossFn(torch.autograd.Function):
     """(x, y) -> (sc, mag) of one resolution; gradient w.r.t. x only (y is the ground truth)."""
 
     @staticmethod
-    def forward(ctx, x, y, win, n, hop, wl=None):
+    def forward(ctx, x, y, win, n, hop, wl):
         x = x.contiguous().float()
         y = y.contiguous().float()
         B, Ln = x.shape
@@ -63,16 +86,12 @@ class _STFTLossFn(torch.autograd.Function):
         x, y, win, tw, sums = ctx.saved_tensors
         B, Ln = x.shape
         coef = torch.stack([g_sc / (torch.sqrt(sums[0]) * torch.sqrt(sums[1])), g_mag / ctx.count]).float().contiguous()
-        if ctx.wl is not None:      # overlap-add as a gather over the window's support: no float atomics
-            nfr = 1 + Ln // ctx.hop
-            frames = torch.empty((B, nfr, ctx.wl), device=x.device, dtype=torch.float32)
-            gx = torch.empty_like(x)
-            check(L.lib().trunet_stft_loss_bwd_gather(ptr(x), ptr(y), ptr(win), ptr(tw), ptr(coef), ptr(frames), ptr(gx),
-                                                      B, Ln, ctx.n, ctx.hop, ctx.wl, L.stream()), "stft_loss_bwd_gather")
-        else:
-            gx = torch.zeros_like(x)
-            check(L.lib().trunet_stft_loss_bwd(ptr(x), ptr(y), ptr(win), ptr(tw), ptr(coef), ptr(gx), B, Ln, ctx.n,
-                                               ctx.hop, L.stream()), "stft_loss_bwd")
+        # overlap-add as a gather over the window's support: no float atomics
+        nfr = 1 + Ln // ctx.hop
+        frames = torch.empty((B, nfr, ctx.wl), device=x.device, dtype=torch.float32)
+        gx = torch.empty_like(x)
+        check(L.lib().trunet_stft_loss_bwd_gather(ptr(x), ptr(y), ptr(win), ptr(tw), ptr(coef), ptr(frames), ptr(gx),
+                                                  B, Ln, ctx.n, ctx.hop, ctx.wl, L.stream()), "stft_loss_bwd_gather")
         return gx, None, None, None, None, None
 
 

@@ -92,55 +92,49 @@ def loss_fn(net, X, ell_p, ell_p_lambda, stft_lambda, mrstftloss, pcen=None, **k
     return loss, output_dic
 
 
-# ----------------------------------------------------------------------------- LR schedule (util.py:81-156)
-def anneal_linear(start, end, proportion):
-    return start + proportion * (end - start)
-
-
-def anneal_cosine(start, end, proportion):
-    return end + (start - end) / 2 * (cos(pi * proportion) + 1)
-
-
-class Phase:
-    def __init__(self, start, end, n_iter, cur_iter, anneal_fn):
-        self.start, self.end, self.n_iter, self.anneal_fn, self.n = start, end, n_iter, anneal_fn, cur_iter
-
-    def step(self):
-        self.n += 1
-        return self.anneal_fn(self.start, self.end, self.n / self.n_iter)
-
-    def reset(self):
-        self.n = 0
-
-    @property
-    def is_done(self):
-        return self.n >= self.n_iter
-
-
+# ----------------------------------------------------------------------------- LR schedule (util.py:110-156)
 class LinearWarmupCosineDecay:
-    """util.py:110-156: linear warm-up lr_max/divider -> lr_max, cosine decay to lr_max/divider/1e4."""
+    """Learning-rate schedule of train.py:102-110 as a closed form of ONE counter.
+
+    A cycle has ``n_iter`` steps: the first ``int(n_iter * warmup_proportion)`` rise from lr_max/divider to lr_max, the
+    rest fall to lr_max/divider/1e4; ``phase`` names the two curve shapes ("linear" or "cosine" each, as in the reference).
+    ``step()`` returns the rate of the next iteration, writes it into every param group and wraps around at the end of
+    the cycle; ``iteration`` resumes inside a cycle.  Pinned by tests/golden/sched.npz (values of the reference class)."""
 
     def __init__(self, optimizer, lr_max, n_iter, iteration=0, divider=25, warmup_proportion=0.3,
                  phase=("linear", "cosine")):
+        for name in phase:
+            if name not in ("linear", "cosine"):
+                raise KeyError(name)
         self.optimizer = optimizer
-        phase1 = int(n_iter * warmup_proportion)
-        phase2 = n_iter - phase1
-        lr_min = lr_max / divider
-        fns = {"linear": anneal_linear, "cosine": anneal_cosine}
-        self.lr_phase = [Phase(lr_min, lr_max, phase1, iteration, fns[phase[0]]),
-                         Phase(lr_max, lr_min / 1e4, phase2, max(0, iteration - phase1), fns[phase[1]])]
-        self.phase = 0 if iteration < phase1 else 1
+        self.shapes = tuple(phase)
+        self.n_iter = n_iter
+        self.n_warm = int(n_iter * warmup_proportion)
+        self.lr_max, self.lr_low, self.lr_end = lr_max, lr_max / divider, lr_max / divider / 1e4
+        self.k = iteration                      # position inside the cycle
+        self.rising = iteration < self.n_warm
+
+    @staticmethod
+    def _curve(shape, a, b, t):
+        """value at fraction t of the way from a to b"""
+        if shape == "linear":
+            return a + t * (b - a)
+        return b + (a - b) / 2 * (cos(pi * t) + 1)
+
+    def lr_at(self, k, rising):
+        if rising:
+            return self._curve(self.shapes[0], self.lr_low, self.lr_max, k / self.n_warm)
+        return self._curve(self.shapes[1], self.lr_max, self.lr_end, (k - self.n_warm) / (self.n_iter - self.n_warm))
 
     def step(self):
-        lr = self.lr_phase[self.phase].step()
+        self.k += 1
+        lr = self.lr_at(self.k, self.rising)
         for group in self.optimizer.param_groups:
             group["lr"] = lr
-        if self.lr_phase[self.phase].is_done:
-            self.phase += 1
-        if self.phase >= len(self.lr_phase):
-            for ph in self.lr_phase:
-                ph.reset()
-            self.phase = 0
+        if self.rising and self.k >= self.n_warm:
+            self.rising = False
+        elif not self.rising and self.k >= self.n_iter:
+            self.k, self.rising = 0, True
         return lr
 
 
