@@ -171,7 +171,7 @@ def _zero_grad_biases(mod):
     return out
 
 
-def _tight(g, ref, name, tol, zero=(), outliers=0.0, maxf=3.0):
+def _tight(g, ref, name, tol, zero=(), outliers=0.0, maxf=3.0, zero_floor=2e-2):
     """Relative L2 AND max-abs error, both relative to the tensor's own scale (no absolute floor).
     ``outliers``: fraction of elements left out of both bounds (largest errors first).  An fp32 and an fp64 run of a
     ReLU network disagree on the mask of the few pre-activations that lie within rounding error of zero (about one in
@@ -182,7 +182,7 @@ def _tight(g, ref, name, tol, zero=(), outliers=0.0, maxf=3.0):
     scale = float(ref.abs().max())
     if name in zero:
         # rounding noise of a sum of ~N*L O(1) terms that cancels exactly (fp32 partial sums of magnitude ~N*L)
-        assert float(g.abs().max()) < 2e-2 and scale < 2e-2, (name, float(g.abs().max()), scale)
+        assert float(g.abs().max()) < zero_floor and scale < zero_floor, (name, float(g.abs().max()), scale)
         return
     d = (g - ref).abs().reshape(-1)
     if outliers > 0:
@@ -245,6 +245,23 @@ def test_block_backward_vs_oracle_f64(name, N):
     pw_bwd, conv_first, relu_bwd_stats + bn_finalize_bwd.  Bounds, scaled to each tensor (no absolute floor): data
     gradients 2e-4 relative L2 outside the 1e-3 of elements hit by ReLU-mask flips (see _tight), parameter gradients
     1e-3 relative L2 and 1e-2 of max|g| per element (measured 2e-5 ... 8e-4; the whole-network bound was 6e-2)."""
+    _block_vs_f64(name, N)
+
+
+@pytest.mark.parametrize("name", ["dsc_k3s1", "dsc_k5s2", "dsc_k3s2", "tr_k3s1", "tr_k5s2", "first_tr", "gru_bi"])
+def test_block_backward_vs_oracle_f64_at_8200_frames(name):
+    """the same per-block comparison at a frame count beyond 8,192 (ragged: 8,200 = 64 tiles + 8 frames), where
+    the persistent workgroups of pw_bwd_kernel (K = 64: dsc_k3s1; K = 128: dsc_k5s2 / dsc_k3s2; <32, true>: the decoder
+    blocks), convt_bwd_kernel<3,1> / <5,2> / <3,2> and dw2_bwd_kernel<5,2> / <3,1> / <3,2> each walk many tiles, every
+    partial weight-gradient image and statistics row is in use, and row offsets pass 2^20 floats."""
+    # 10x the frames of the N = 777 case: the rounding noise of the analytically-zero bias sums grows with the square
+    # root of the number of terms (floor 2e-2 -> 6.5e-2), and ~10x as many ReLU-mask flips between fp32 and fp64 land in
+    # every parameter gradient (each moves it by ~3e-4 of its norm, in random directions: bound 1e-3 -> 2e-3; measured
+    # worst case 1.1e-3, GRU.weight_ih_l0)
+    _block_vs_f64(name, 8200, ptol=2e-3, zero_floor=2e-2 * (8200 / 777.0) ** 0.5)
+
+
+def _block_vs_f64(name, N, ptol=1e-3, zero_floor=2e-2):
     from oracle import network_ref as nr, weights as W
     from tinyrecurrentunet_amd import network as hn
     cls, args = BLOCKS[name]
@@ -268,7 +285,7 @@ def test_block_backward_vs_oracle_f64(name, N):
     zero = _zero_grad_biases(mod)
     for pn, p in mod.named_parameters():
         # a single mask flip moves a weight gradient by ~3e-4 of its norm and one element by up to ~5e-3 of max|g|
-        _tight(p.grad, pd[pn].grad, pn, 1e-3, zero, maxf=10.0)
+        _tight(p.grad, pd[pn].grad, pn, ptol, zero, maxf=10.0 * 1e-3 / ptol, zero_floor=zero_floor)
     for bn_, b in mod.named_buffers():
         if b.is_floating_point():
             assert _rel(b, dict(ref.named_buffers())[bn_]) < 1e-5, bn_
