@@ -7,6 +7,7 @@
 // weights as MFMA A fragments in LDS (packed per launch from the fp32 master weights); fp32 accumulators, statistics,
 // coefficients, weight gradients.  Taps, strides, F.pad, crops and the concat of network.py:95-98 stay whole-row offsets /
 // extra segments.
+#include <type_traits>
 #include "bf16_common.hpp"
 
 namespace {
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(const trunet_bgemm_args a
         for (int t = 0; t < NRT; ++t) {
             if (t >= nrt) continue;
             const int m = (rt0 + t) * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-            if (!(c & 1) && m < a.M) { pp[2 * m] = sacc[t][0]; pp[2 * m + 1] = sacc[t][1]; }
+            if (butterfly16_writer(c) && m < a.M) { pp[2 * m] = sacc[t][0]; pp[2 * m + 1] = sacc[t][1]; }
         }
     }
 }
@@ -426,14 +427,15 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
             }
         }
     }
-    // ---- DG: this wave's data-gradient tiles g = wave + 8 i -> (source row tile g / 2, frame half g % 2)
+    // ---- DG: this wave's data-gradient tiles g = (7 - wave) + 8 i -> (source row tile g / 2, frame half g % 2): the weight-
+    // gradient tiles go round-robin from wave 0, so with 12 + 12 tiles (decoder layers) every wave gets three, not 4 / 2
     int d_seg[BW_MAXG], d_rtl[BW_MAXG], d_rtg[BW_MAXG], d_og[BW_MAXG];      // segment, row tile in it / overall, first octet
     float sacc[BW_MAXG][2];
 #pragma unroll
     for (int i = 0; i < BW_MAXG; ++i) {
         d_seg[i] = -1; d_rtl[i] = 0; d_rtg[i] = 0; d_og[i] = 0; sacc[i][0] = 0.f; sacc[i][1] = 0.f;
         if constexpr (DG) {
-            const int g = wave + 8 * i, rtg = g >> 1;
+            const int g = (7 - wave) + 8 * i, rtg = g >> 1;     // reversed: the waves with fewer weight-gradient tiles take more
             int rbase = 0, obase = 0;
             for (int s = 0; s < a.nseg; ++s) {
                 const int nr = a.seg[s].nchan >> 5;
@@ -506,12 +508,42 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
             }
         }
     };
-    auto store = [&](const Info& f, unsigned char* buf, const Stage& r) {
-        const bool fin = f.chunk * BW_F + lane < a.N;
+    // DG: request the gradient already stored where this step's data-gradient tiles accumulate (skip connections).  Issued one
+    // step ahead of its use: read at the point of use it put one full HBM latency into every step of the five encoder launches
+    auto issue_oin = [&](const Info& f, u32x2 (&o)[DG ? BW_MAXG : 1][4]) {
+        if constexpr (DG) {
+            const int h = lane >> 5, c = lane & 31;
+#pragma unroll
+            for (int i = 0; i < BW_MAXG; ++i) {
+                if (d_seg[i] < 0 || !(dg.flags[d_seg[i]] & 8)) continue;
+#if defined(BW_ABL) && (BW_ABL & 64)     // diagnostic: the accumulate operands are not loaded
+                if (a.N >= 0) continue;
+#endif
+                bool valid; int q;
+                pos(pc_d[i], f.p, valid, q);
+                if (!valid) continue;
+                const trunet_bseg& sg = a.seg[d_seg[i]];
+                const int cb = ((7 - wave) + 8 * i) & 1;
+                const int nn = f.chunk * BW_F + 32 * cb + c;
+                const u32x2* outp = (const u32x2*)dg.out[d_seg[i]];
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+                    o[i][g4] = outp[(((size_t)(d_rtl[i] * 4 + g4) * sg.L + q) * a.NP + nn) * 2 + h];
+            }
+        }
+    };
+    // FULL: all 64 frames of the step are real frames (every chunk but the last one or two): no per-lane frame selects
+    auto store = [&](auto full_tag, const Info& f, unsigned char* buf, const Stage& r) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const bool fin = FULL || f.chunk * BW_F + lane < a.N;
 #pragma unroll
         for (int j = 0; j < BW_MAXD; ++j) {
             const int oct = wave + 8 * j;
             if (oct < moct) {
+#if defined(BW_ABL) && (BW_ABL & 1)      // diagnostic (wrong results): no BatchNorm-backward prologue
+                *(u32x4*)(buf + oct * BW_OS + lane * 16) = r.dy[j] ^ r.z[j];
+                continue;
+#endif
                 float v[8], w[8];
                 bf_unpack8(r.dy[j], v);
                 const float* cd = Cd + oct * 24;
@@ -525,7 +557,7 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    v[e] = fin ? v[e] : 0.f;
+                    if (!FULL) v[e] = fin ? v[e] : 0.f;
                     bsum[j][e] += v[e];
                 }
                 *(u32x4*)(buf + oct * BW_OS + lane * 16) = bf_pack8(v);
@@ -539,7 +571,11 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
                 pos(pc_s[j], f.p, valid, q);
                 if (valid) {
                     if constexpr (DG) *(u32x4*)(buf + (moct + soct_total + soct_g[j]) * BW_OS + lane * 16) = r.s[j];
+#if defined(BW_ABL) && (BW_ABL & 2)      // diagnostic (wrong results): no source prologue
+                    if (true) {
+#else
                     if (SMODE == TRUNET_PRO_NONE && (sg.nchan & 7) == 0) {
+#endif
                         *(u32x4*)(buf + (moct + soct_g[j]) * BW_OS + lane * 16) = r.s[j];       // raw operand
                     } else {
                         const float* cs = Cs + soct_g[j] * 16;
@@ -550,13 +586,16 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
             }
         }
     };
-    auto mma = [&](const Info& f, const unsigned char* buf) {
+    auto mma = [&](const Info& f, const unsigned char* buf, const u32x2 (&oin)[DG ? BW_MAXG : 1][4]) {
 #pragma unroll
         for (int i = 0; i < BW_MAXT; ++i) {
             if (t_rt[i] < 0) continue;
             bool valid; int q;
             pos(pc_t[i], f.p, valid, q);
             if (!valid) continue;
+#if defined(BW_ABL) && (BW_ABL & 4)      // diagnostic: no weight-gradient MFMAs
+            continue;
+#endif
 #pragma unroll
             for (int kk = 0; kk < BW_F / 16; ++kk) {
                 const bf16x8 af = lds_frag(buf, 4 * t_rt[i], 16 * kk, lane);
@@ -572,7 +611,7 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
                 bool valid; int q;
                 pos(pc_d[i], f.p, valid, q);
                 if (!valid) continue;
-                const int cb = (wave + 8 * i) & 1;
+                const int cb = ((7 - wave) + 8 * i) & 1;
                 f32x16 d;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) d[r] = 0.f;
@@ -588,6 +627,10 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
                 const int nn = f.chunk * BW_F + 32 * cb + c;
                 const bool fin = nn < a.N;
                 float st1[16], st2[16];
+#if defined(BW_ABL) && (BW_ABL & 16)     // diagnostic: no data-gradient epilogue (one guarded store keeps the MFMAs alive)
+                if (a.N < 0) ((float*)dg.out[0])[lane] = d[0] + d[5] + d[10] + d[15];
+                continue;
+#endif
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int og = d_og[i] + g4;
@@ -596,7 +639,7 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
 #pragma unroll
                     for (int e = 0; e < 4; ++e) val[e] = d[4 * g4 + e];
                     if (flags & 8) {        // accumulate onto the gradient already stored there (skip connection)
-                        const u32x2 o = outp[eidx];
+                        const u32x2 o = oin[i][g4];
                         val[0] += bf_lo(o[0]); val[1] += bf_hi(o[0]); val[2] += bf_lo(o[1]); val[3] += bf_hi(o[1]);
                     }
                     f32x4 muv = {0.f, 0.f, 0.f, 0.f};
@@ -611,6 +654,9 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
                     u32x2 o;
                     o[0] = bf_pack(val[0], val[1]);
                     o[1] = bf_pack(val[2], val[3]);
+#if defined(BW_ABL) && (BW_ABL & 32)     // diagnostic: the data gradient is computed but not stored
+                    if (a.N < 0)
+#endif
                     outp[eidx] = o;
                     const float rv[4] = {bf_lo(o[0]), bf_hi(o[0]), bf_lo(o[1]), bf_hi(o[1])};
 #pragma unroll
@@ -620,6 +666,9 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
                         st2[4 * g4 + e] = x * (zv[e] - muv[e]);
                     }
                 }
+#if defined(BW_ABL) && (BW_ABL & 8)      // diagnostic: no statistics exchange
+                if (a.N < 0)
+#endif
                 if (flags & 4) {
                     sacc[i][0] += butterfly16(st1, c);
                     sacc[i][1] += butterfly16(st2, c);
@@ -652,19 +701,31 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
     if (s_begin < s_end) { issue(fa, sa); advance(nx); }
     if (s_begin + 1 < s_end) { fb = nx; issue(fb, sb); advance(nx); }
     if (DEPTH == 3 && s_begin + 2 < s_end) { fc = nx; issue(fc, sc); advance(nx); }
-    auto step = [&](int st, Info& f, Stage& r) {
+    typedef u32x2 OIn[DG ? BW_MAXG : 1][4];
+    OIn o0, o1, o2;                                // accumulate operands of the data-gradient tiles: current / next step
+    if (DG && s_begin < s_end) issue_oin(fa, o0);
+    // fnext: the step after this one (the next stage's Info: a stage is re-issued only inside its own step)
+    auto step = [&](int st, Info& f, Stage& r, const Info& fnext, const OIn& ocur, OIn& onext) {
         unsigned char* buf = smem_ + ((st - s_begin) & 1) * img_bytes;
-        store(f, buf, r);
+        const bool full = (f.chunk + 1) * BW_F <= a.N;        // uniform
+        if (full) store(std::true_type{}, f, buf, r);
+        else store(std::false_type{}, f, buf, r);
         const Info cur = f;
         if (st + DEPTH < s_end) { f = nx; issue(f, r); advance(nx); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        mma(cur, buf);
+        if (DG && st + 1 < s_end) issue_oin(fnext, onext);
+        mma(cur, buf, ocur);
     };
     for (int st = s_begin; st < s_end; st += DEPTH) {
-        step(st, fa, sa);
-        if (st + 1 < s_end) step(st + 1, fb, sb);
-        if (DEPTH == 3 && st + 2 < s_end) step(st + 2, fc, sc);
+        if (DEPTH == 2) {
+            step(st, fa, sa, fb, o0, o1);
+            if (st + 1 < s_end) step(st + 1, fb, sb, fa, o1, o0);
+        } else {
+            step(st, fa, sa, fb, o0, o1);
+            if (st + 1 < s_end) step(st + 1, fb, sb, fc, o1, o2);
+            if (st + 2 < s_end) step(st + 2, fc, sc, fa, o2, o0);
+        }
     }
 
     // ---- partial image of dW (rows m = dz channel, columns c = source channel) and db
@@ -688,11 +749,11 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
 #pragma unroll
         for (int i = 0; i < BW_MAXG; ++i) {
             if (d_seg[i] < 0 || !(dg.flags[d_seg[i]] & 4)) continue;
-            const int cb = (wave + 8 * i) & 1;
+            const int cb = ((7 - wave) + 8 * i) & 1;
             const int nch = a.seg[d_seg[i]].nchan;
             const int ch = d_rtl[i] * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
             float* pp = dg.partials[d_seg[i]] + ((size_t)(blockIdx.x * 2 + cb) * nch + ch) * 2;
-            if (!(c & 1)) { pp[0] = sacc[i][0]; pp[1] = sacc[i][1]; }
+            if (butterfly16_writer(c)) { pp[0] = sacc[i][0]; pp[1] = sacc[i][1]; }
         }
     }
     if (a.b_partials) {

@@ -63,23 +63,32 @@ __device__ __forceinline__ u32x4 bf_pack8(const float (&f)[8]) {
     return v;
 }
 
-// sum each of 16 per-lane values over the 32 lanes of a half-wave; lane c returns the total of value butterfly16_index(c)
-// (16 cross-lane exchanges instead of 80, and ONE live register instead of 16)
+// sum each of 16 per-lane values over the 32 lanes of a half-wave; every lane c returns the total of value
+// butterfly16_index(c) (16 cross-lane exchanges instead of 80, and ONE live register instead of 16); lanes c and c ^ 16
+// hold the same total: butterfly16_writer(c) picks one.  The 15 halving exchanges stay inside a row of 16 lanes and are
+// DPP moves (partner = row mirror / half-row mirror / quad reverse / quad swap: it differs in the stage's bit and agrees in
+// the bits already consumed, which is all a butterfly sum needs); the last one crosses rows with v_permlane16_swap.  As
+// __shfl_xor they were 16 ds_bpermute round trips in five dependent stages, ~500 cycles of LDS latency per call.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
 __device__ __forceinline__ float butterfly16(const float (&x)[16], int c) {
     float y8[8], y4[4], y2[2];
-    const bool b16 = c & 16, b8 = c & 8, b4 = c & 4, b2 = c & 2;
+    const bool b8 = c & 8, b4 = c & 4, b2 = c & 2, b1 = c & 1;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) y8[i] = (b16 ? x[i + 8] : x[i]) + __shfl_xor(b16 ? x[i] : x[i + 8], 16);
+    for (int i = 0; i < 8; ++i) y8[i] = (b8 ? x[i + 8] : x[i]) + dpp_mov<0x140>(b8 ? x[i] : x[i + 8]);          // row_mirror
 #pragma unroll
-    for (int i = 0; i < 4; ++i) y4[i] = (b8 ? y8[i + 4] : y8[i]) + __shfl_xor(b8 ? y8[i] : y8[i + 4], 8);
+    for (int i = 0; i < 4; ++i) y4[i] = (b4 ? y8[i + 4] : y8[i]) + dpp_mov<0x141>(b4 ? y8[i] : y8[i + 4]);      // row_half_mirror
 #pragma unroll
-    for (int i = 0; i < 2; ++i) y2[i] = (b4 ? y4[i + 2] : y4[i]) + __shfl_xor(b4 ? y4[i] : y4[i + 2], 4);
-    const float y1 = (b2 ? y2[1] : y2[0]) + __shfl_xor(b2 ? y2[0] : y2[1], 2);
-    return y1 + __shfl_xor(y1, 1);
+    for (int i = 0; i < 2; ++i) y2[i] = (b2 ? y4[i + 2] : y4[i]) + dpp_mov<0x1B>(b2 ? y4[i] : y4[i + 2]);       // quad_perm 3,2,1,0
+    const float y1 = (b1 ? y2[1] : y2[0]) + dpp_mov<0xB1>(b1 ? y2[0] : y2[1]);                                  // quad_perm 1,0,3,2
+    // rows (c & 16): vdst's odd rows <-> vsrc's even rows, so the two results are (even row, even row) and (odd row, odd row)
+    const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, y1), __builtin_bit_cast(unsigned, y1), false, false);
+    return __builtin_bit_cast(float, (unsigned)sw[0]) + __builtin_bit_cast(float, (unsigned)sw[1]);
 }
-__device__ __forceinline__ int butterfly16_index(int c) {
-    return ((c & 16) ? 8 : 0) + ((c & 8) ? 4 : 0) + ((c & 4) ? 2 : 0) + ((c & 2) ? 1 : 0);
-}
+__device__ __forceinline__ int butterfly16_index(int c) { return c & 15; }
+__device__ __forceinline__ bool butterfly16_writer(int c) { return !(c & 16); }
 
 constexpr int BW_F = 64;                         // frames per step
 constexpr int BW_OS = BW_F * 16 + 64;            // LDS bytes between octets

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(BCT_THREADS, 1) void bconvt_bwd_kernel(const trunet
         const int r = butterfly16_index(c);
         const int ch = rt * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
         float* pp = a.partials + ((size_t)(blockIdx.x * 2 + cb) * 64 + ch) * 2;
-        if (!(c & 1)) { pp[0] = sacc0; pp[1] = sacc1; }
+        if (butterfly16_writer(c)) { pp[0] = sacc0; pp[1] = sacc1; }
     }
     if (a.b_partials) {
 #pragma unroll

@@ -59,6 +59,9 @@ __device__ __forceinline__ void it_enter_tile(const trunet_gemm_args& a, ChunkIt
         it.placed = true;
     }
     it.s = 0; it.cc = 0; it.ach = 0; it.cbase = 0;
+#ifdef GEMM_SIMPLE_IT      // diagnostic: one always-valid segment (upper bound of what cheaper iterators can give)
+    return;
+#endif
     while (it.s < a.nseg - 1 && !seg_pos(a.seg[it.s], it.p).valid) {   // host contract: >= 1 valid segment
         it.ach += (a.seg[it.s].nchan + KC - 1) / KC;
         it.cbase += a.seg[it.s].nchan;
@@ -69,6 +72,14 @@ __device__ __forceinline__ void it_enter_tile(const trunet_gemm_args& a, ChunkIt
 // true when the chunk after `it` belongs to another tile (or the stream ends)
 template <int KC, int FT = NT>
 __device__ __forceinline__ bool it_next(const trunet_gemm_args& a, ChunkIt& it) {
+#ifdef GEMM_SIMPLE_IT
+    if (++it.cc < (a.seg[0].nchan + KC - 1) / KC) return false;
+    it.cc = 0;
+    ++it.tile;
+    if (++it.p == a.p_begin + a.P) { it.p = a.p_begin; it.n0 += FT; }
+    it.valid = it.tile < it.tile_end;
+    return true;
+#endif
     const int nck = (a.seg[it.s].nchan + KC - 1) / KC;
     if (++it.cc < nck) return false;
     it.ach += nck;
