@@ -21,6 +21,7 @@
 //     sources for the whole kernel (plus, with six row tiles, a second one on alternate tiles), keeps the matching
 //     W^T fragments in registers, and runs the epilogue (accumulate / ReLU mask / statistics / store) itself.
 // The two roles execute different loops with the same barrier sequence.
+#include <cstdlib>
 #include <type_traits>
 #include "common.hpp"
 
@@ -115,7 +116,13 @@ struct DRun {
 
 // AK: k-pairs of the data-gradient A fragments = padded dz rows / 2 (32 for M <= 64, 64 for M <= 128)
 // SEC: data-gradient waves carry a second row tile (six row tiles over four waves); it never has statistics
-template <int AK, bool SEC>
+// KSPLIT (layers with TWO source row tiles, e.g. encoder.1's 64 -> 128): the four data-gradient waves work on EVERY tile,
+// wave j on row tile j & 1 and the K half j >> 1 of the dz rows; the two halves of a row tile meet through LDS (each wave
+// hands over 8 of its 16 accumulator registers and finishes -- accumulate / mask / statistics / store -- the 8 rows it
+// keeps).  Without it two waves alternated whole tiles: the active wave carried AK MFMAs next to its SIMD partner's
+// weight-gradient MFMAs while the other pair of SIMDs idled, 96 instead of 64 MFMA times per tile (measured 60 TF against
+// 85 TF for the four-row-tile layers).
+template <int AK, bool SEC, bool KSPLIT = false>
 __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args A, const PwbSched sch, const int NB,
                                                         const int rows) {
     const trunet_wgrad_args& a = A.w;
@@ -134,6 +141,9 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
     float* R_lds = smem;
     f32x4* CA = (f32x4*)(R_lds + (size_t)NB * SLOT);      // [MA] dz coefficients
     f32x4* CB = CA + MA;                                     // [sum nchan] (c0, c1, lo, mean) of the sources
+    int ntot_ = 0;
+    for (int s = 0; s < a.nseg; ++s) ntot_ += a.seg[s].nchan;
+    float* XB = (float*)(CB + ntot_);                        // KSPLIT: [tile parity][row tile][sender half][8][64] floats
 
     for (int r = tid; r < MA; r += 512) {
         const int ch = min(r, a.M - 1) + a.a_m_off;
@@ -417,6 +427,137 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
         // =================== data-gradient role (no DMA, no prologue pass: LDS reads, MFMAs, epilogue)
         // (s_setprio 1 for these waves was measured: 4 % slower at 128 channels, neutral at 64)
         const int j = wave - 4;
+        if constexpr (KSPLIT) {
+            constexpr int AH = AK / 2;                 // k-pairs per wave
+            const int rt = j & 1, kh = j >> 1;         // row tile, K half (uniform)
+            // the row tile's segment / 32-channel tile / coefficient base
+            int useg = -1, uct = 0, ucb = 0;
+            {
+                int g = rt, cb = 0;
+#pragma unroll
+                for (int s = 0; s < TRUNET_MAX_SEG; ++s) {
+                    if (s < a.nseg && g >= 0 && useg < 0) {
+                        const int nt = (a.seg[s].nchan + 31) / 32;
+                        if (g < nt) { useg = s; uct = g; ucb = cb; }
+                        else { g -= nt; cb += a.seg[s].nchan; }
+                    }
+                }
+            }
+            useg = pwb_uniform(useg); uct = pwb_uniform(uct); ucb = pwb_uniform(ucb);
+            const int uflags = pwb_uniform(A.dg[useg].flags);
+            const trunet_seg& usg = a.seg[useg];
+            float af[AH];
+            {
+                const int ch = 32 * uct + c;
+                const bool chok = ch < usg.nchan;
+                const float* wp = A.W + (size_t)a.w_m_off * a.ldw_m + (size_t)min(ch, usg.nchan - 1) * a.ldw_c + usg.woff;
+#pragma unroll
+                for (int kk = 0; kk < AH; ++kk) {
+                    const int m = 2 * (kh * AH + kk) + h;
+                    const float v = wp[(size_t)min(m, a.M - 1) * a.ldw_m];
+                    af[kk] = (chok && m < a.M) ? v : 0.f;
+                }
+            }
+            float sa1[8], sa2[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { sa1[i] = 0.f; sa2[i] = 0.f; }
+            const int rowsel = 16 * kh;               // this wave finishes rows (i & 3) + 8 (i >> 2) + 16 kh + 4 h of the tile
+            const f32x4* CBs = CB + ucb + 32 * uct + 4 * h + rowsel;
+            int t0 = t_begin;
+            while (t0 < t_end) {
+                const int pi = t0 / nfc;
+                const int p = a.p_begin + pi;
+                const int t1 = min(t_end, (pi + 1) * nfc);
+                const PSegPos sp = pwb_seg_pos(usg, p);
+                const bool pvalid = sp.valid && (uflags & TRUNET_DG_STORE);
+                const size_t dstride = pwb_uniform((size_t)usg.L * a.NP);
+                const size_t o0 = ((size_t)(32 * uct + rowsel) * usg.L + (sp.valid ? sp.q : 0)) * a.NP;
+                const __amdgpu_buffer_rsrc_t rz = pwb_rsrc(pwb_uniform(A.dg[useg].zmask ? A.dg[useg].zmask + o0 : A.dg[useg].out + o0));
+                const __amdgpu_buffer_rsrc_t ro = pwb_rsrc(pwb_uniform(A.dg[useg].out + o0));
+                const int rowb = (int)(dstride * sizeof(float));
+                const int voff = (int)((4 * h * dstride + c) * sizeof(float));
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_barrier();                     // tile t0 staged and transformed
+                asm volatile("" ::: "memory");
+                int slot = 0;
+                for (int t = t0; t < t1; ++t) {
+                    const float* S = R_lds + (size_t)slot * SLOT;
+                    const int n0 = pwb_uniform((t - pi * nfc) * WFC);
+                    const int nb = n0 * (int)sizeof(float);
+                    float* xs = XB + (size_t)(((t & 1) * 2 + rt) * 2) * 512;       // [sender half][8][64]
+                    float zv[8], ov[8];
+                    f32x16 dacc;
+                    if (pvalid) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { zv[i] = 0.f; ov[i] = 0.f; }
+                        if ((uflags & TRUNET_DG_MASK) && !(PWB_ABL & 1)) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) zv[i] = pwb_bload(rz, voff, ((i & 3) + 8 * (i >> 2)) * rowb + nb);
+                        }
+                        if ((uflags & TRUNET_DG_ACCUM) && !(PWB_ABL & 1)) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) ov[i] = pwb_bload(ro, voff, ((i & 3) + 8 * (i >> 2)) * rowb + nb);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) dacc[r] = 0.f;
+                        const float* Sb = S + (size_t)kh * AH * (2 * WFC) + h * WFC + (c & 3);
+                        const int cpc = c >> 2;
+#pragma unroll
+                        for (int kk = 0; kk < ((PWB_ABL & 32) ? 1 : AH); ++kk) {
+                            const float b = Sb[kk * (2 * WFC) + 4 * (cpc ^ (kk & 7))];
+                            dacc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], b, dacc, 0, 0, 0);
+                        }
+                        // hand over the 8 registers of the rows the partner wave finishes
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) xs[(kh * 8 + i) * 64 + lane] = kh ? dacc[i] : dacc[8 + i];
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();                // every LDS read of tile t is done; the halves are in LDS
+                    asm volatile("" ::: "memory");
+                    if (pvalid) {
+                        const bool fin = n0 + c < a.N;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int ml = (i & 3) + 8 * (i >> 2);
+                            float val = (kh ? dacc[8 + i] : dacc[i]) + xs[((1 - kh) * 8 + i) * 64 + lane];
+                            if (uflags & TRUNET_DG_ACCUM) val += ov[i];
+                            f32x4 k = {0.f, 0.f, 0.f, 0.f};
+                            if (uflags & TRUNET_DG_MASK) {
+                                k = CBs[ml];
+                                val = (fmaf(k[0], zv[i], k[1]) > 0.f) ? val : 0.f;
+                            }
+                            if (!(PWB_ABL & 2)) pwb_bstore(ro, voff, ml * rowb + nb, val);
+                            if (uflags & TRUNET_DG_STATS) {
+                                const float x = fin ? val : 0.f;
+                                sa1[i] += x;
+                                sa2[i] = fmaf(x, zv[i] - k[3], sa2[i]);
+                            }
+                        }
+                    }
+                    slot = (slot + 1 == NB) ? 0 : slot + 1;
+                }
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_barrier();                     // ring is reused by the next run of tiles
+                asm volatile("" ::: "memory");
+                t0 = t1;
+            }
+            if (uflags & TRUNET_DG_STATS) {
+                const trunet_dgrad_out& dg = A.dg[useg];
+                const int nch = usg.nchan;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float s1 = half_wave_sum(sa1[i]);
+                    const float s2 = half_wave_sum(sa2[i]);
+                    const int ch = 32 * uct + rowsel + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (c == 0 && ch < nch) {
+                        float* pp = dg.partials + ((size_t)(blockIdx.x * PWB_SHARE) * nch + ch) * 2;
+                        pp[0] = s1;
+                        pp[1] = s2;
+                    }
+                }
+            }
+            return;
+        }
         auto make_unit = [&](int rt, int period, int phase, int share) __attribute__((always_inline)) {
             DUnit u;
             u.seg = -1; u.ct = 0; u.cb = 0; u.flags = 0; u.mask = period - 1; u.phase = phase; u.share = share;
@@ -655,7 +796,9 @@ extern "C" int trunet_pw_bwd(const trunet_pwbwd_args* H, void* stream) {
         sch.rt2[j] = -1; sch.period2[j] = 1; sch.phase2[j] = 0; sch.share2[j] = 0;
     }
     bool sec = false;
-    if (ktiles == 2) {          // two waves per row tile, alternating tiles
+    static const bool ksplit_ok = !(getenv("TRUNET_PWB_KSPLIT") && getenv("TRUNET_PWB_KSPLIT")[0] == '0');
+    const bool ksplit = ktiles == 2 && ksplit_ok;      // two row tiles: every wave on every tile, K halves (KSPLIT)
+    if (ktiles == 2) {          // (fallback) two waves per row tile, alternating tiles
         for (int j = 0; j < 4; ++j) { sch.rt[j] = j & 1; sch.period[j] = 2; sch.phase[j] = j >> 1; sch.share[j] = j >> 1; }
     } else if (ktiles == 4) {   // one row tile per wave, every tile
         for (int j = 0; j < 4; ++j) sch.rt[j] = j;
@@ -680,7 +823,7 @@ extern "C" int trunet_pw_bwd(const trunet_pwbwd_args* H, void* stream) {
     }
     const int rows = 2 * MA + ntot;
     const size_t slot = (size_t)rows * WFC * sizeof(float);
-    const size_t fixed = (size_t)(MA + ntot) * sizeof(f32x4);
+    const size_t fixed = (size_t)(MA + ntot) * sizeof(f32x4) + (ksplit ? 2 * 2 * 2 * 8 * 64 * sizeof(float) : 0);
     int NB = (int)((160 * 1024 - fixed) / slot);
     if (NB > 4) NB = 4;
     if (NB < 2) return TRUNET_ENOTSUP;
@@ -692,16 +835,18 @@ extern "C" int trunet_pw_bwd(const trunet_pwbwd_args* H, void* stream) {
             if (hipMemsetAsync(dg.partials, 0, bytes, st) != hipSuccess) return TRUNET_ELAUNCH;
         }
     }
-#define PWB_LAUNCH(AK_, SEC_)                                                                                          \
+#define PWB_LAUNCH(AK_, SEC_, KS_)                                                                                     \
     do {                                                                                                               \
-        auto kern = pw_bwd_kernel<AK_, SEC_>;                                                                          \
+        auto kern = pw_bwd_kernel<AK_, SEC_, KS_>;                                                                        \
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
             return TRUNET_ELAUNCH;                                                                                     \
         hipLaunchKernelGGL(kern, dim3(PWB_GRID), dim3(512), lds, st, *H, sch, NB, rows);                               \
     } while (0)
-    if (MA == 64 && sec) PWB_LAUNCH(32, true);
-    else if (MA == 64) PWB_LAUNCH(32, false);
-    else PWB_LAUNCH(64, false);
+    if (MA == 64 && sec) PWB_LAUNCH(32, true, false);
+    else if (MA == 64 && ksplit) PWB_LAUNCH(32, false, true);
+    else if (MA == 64) PWB_LAUNCH(32, false, false);
+    else if (ksplit) PWB_LAUNCH(64, false, true);
+    else PWB_LAUNCH(64, false, false);
 #undef PWB_LAUNCH
     return trunet_launch_status();
 }
