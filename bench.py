@@ -191,7 +191,7 @@ def streaming(args, dev, emit=True):
     dt = (time.time() - t0) / args.steps
     # roofline of the forward kernel: HIP events on the launch stream around direct (un-graphed) calls
     roof = None
-    if not args.tgru:
+    if True:
         with torch.no_grad():
             evs = []
             for _ in range(20):
@@ -203,12 +203,16 @@ def streaming(args, dev, emit=True):
             torch.cuda.synchronize()
         kms = pctl([a.elapsed_time(b) for a, b in evs], 0.5)
         flops = streams * (FLOPS_PER_FRAME_STEP / 3.0)            # forward: 31,363,072 flop per frame
+        if args.tgru:       # + one GRU time step per (stream, position): W_ih (384 x 64), W_hh (384 x 128), conv (64 x 128)
+            flops += streams * 2.0 * (384 * 64 + 384 * 128 + 64 * 128) * 16
         ach = flops / (kms * 1e-3) / 1e12
-        folded = net.__dict__.get("_folded_cache") is not None
-        roof = {"bound": "mfma", "kernel": "stream_fwd_kernel" if folded else "layer-by-layer launches",
+        folded = bool(net.__dict__.get("_folded_cache")) and (state is None or state.layout == "folded")
+        roof = {"bound": "mfma", "kernel": ("stream_fwd_kernel<%s>" % ("true" if args.tgru else "false")) if folded
+                else "layer-by-layer launches",
                 "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4),
                 "traffic": None, "avg_launch_ms": round(kms, 4),
-                "algorithmic_bytes_per_launch": streams * 12336,   # features in + output out per frame
+                # features in + output out per frame (+ the hidden state read and written: 2 x 8 KB)
+                "algorithmic_bytes_per_launch": streams * (12336 + (16384 if args.tgru else 0)),
                 "note": "per-frame independent eval forward, one workgroup per frame: bound by the fp32 MFMA rate "
                         "(31.4 Mflop vs 12.3 KB per frame)"}
     cpu = None

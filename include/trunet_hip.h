@@ -333,19 +333,27 @@ int trunet_phm_fwd(const float* mix_ri, const float* est_ri, float* out, int64_t
 int trunet_phm_bwd(const float* mix_ri, const float* est_ri, const float* g_out, float* g_mix_ri, float* g_est_ri,
                    int64_t n, float beta, void* stream);
 
-/* ---- eval-mode single-launch forward (rt.py:20-27 protocol, onnx.py:14-44 artefact role) ----
- * The whole TRU-Net forward of network.py:153-171 (R1-R4, TGRU not executed) for N independent frames in ONE launch:
- * x (N, Cin, 257) -> y (N, 8, 257), Cin in {3, 4}.  BatchNorm (eval: running statistics) is folded into the conv in front
- * of it by the exporter; `blob` is the exported weight image (32-row tiles for the 128-channel encoder layers, 16-row tiles
- * for the GRU projection and every 64-channel layer, each in MFMA fragment order) and h_offsets the 26
- * element offsets of its sections (first conv | 5 encoder pw | 5 depthwise | GRU projection | W_hh, b_hh | FGRU conv |
- * 6 decoder pw | 5 transposed convs | last transposed conv), as written by tinyrecurrentunet_amd/export.py.  Every
- * workgroup takes one frame at a time through all layers in its own LDS; `scratch` holds the skip tensors of the frames
- * in flight: trunet_stream_fwd_scratch_floats(trunet_stream_fwd_grid(N)) floats. */
+/* ---- eval-mode single-launch forward (SURVEY 8f ranks 1 + 2; rt.py:20-27 protocol, onnx.py:14-44 artefact role) ----
+ * The whole TRU-Net forward of network.py:153-171 (R1-R4) for N frames in ONE launch: x (N, Cin, 257) -> y (N, 8, 257),
+ * Cin in {3, 4}.  BatchNorm (eval: running statistics) is folded into the conv in front of it by the exporter; `blob` is
+ * the exported weight image of `blob_numel` floats (32-row tiles for the 128-channel encoder layers, 16-row tiles for the
+ * GRU projection and every 64-channel layer, each in MFMA fragment order) and h_offsets the 30 element offsets of its
+ * sections (first conv | 5 encoder pw | 5 depthwise | GRU projection | W_hh, b_hh | FGRU conv | 6 decoder pw | 5 transposed
+ * convs | last transposed conv | TGRU r/z rows, n rows of W_ih, n rows of W_hh, TGRU conv -- the last four 0 when the
+ * time-recurrent block was not exported), as written by tinyrecurrentunet_amd/export.py.  Every workgroup takes one frame
+ * at a time through all layers in its own LDS; `scratch` holds the skip tensors of the frames in flight:
+ * trunet_stream_fwd_scratch_floats(trunet_stream_fwd_grid(N)) floats.
+ * h_in == h_out == NULL: every frame independent (the reference's forward, TGRU not executed, R4).
+ * h_in, h_out != NULL (the causal stream of rt.py:20-27 / stream.py:83-109; network.py:150, GRUBlock :45-58): the N frames
+ * are ONE new frame of N streams; the TGRU block runs one GRU time step per (stream, frequency position) between
+ * FGRU.conv and decoder.0; h_in / h_out are (N, 128, 16) fp32 hidden states (may be the same buffer: updated in place).
+ * trunet_stream_fwd_check: TRUNET_OK when every section (fragment over-reads included) lies inside the blob; the launch
+ * entry point runs it first, so a truncated or foreign image returns TRUNET_EINVAL instead of faulting. */
 int trunet_stream_fwd_grid(int N);
 size_t trunet_stream_fwd_scratch_floats(int grid);
-int trunet_stream_fwd(const float* x, float* y, const float* blob, const int32_t* h_offsets, int n_offsets, float* scratch,
-                      int N, int Cin, void* stream);
+int trunet_stream_fwd_check(const int32_t* h_offsets, int n_offsets, int64_t blob_numel, int Cin);
+int trunet_stream_fwd(const float* x, float* y, const float* blob, const int32_t* h_offsets, int n_offsets,
+                      int64_t blob_numel, float* scratch, const float* h_in, float* h_out, int N, int Cin, void* stream);
 
 /* ---- input pipeline on the GPU ----
  * DataAugment.__call__ + the clean/noise mix (dataset.py:116-126, :380) for a whole batch resident in HBM:

@@ -72,7 +72,9 @@ def _decode16(sec, M, K):
 def test_fold_layout_and_batchnorm_folding():
     net = _net()
     blob, offs, cin = export.fold(net)
-    assert cin == 4 and blob.dtype == np.float32 and offs.dtype == np.int32 and len(offs) == 26
+    assert cin == 4 and blob.dtype == np.float32 and offs.dtype == np.int32 and len(offs) == 30
+    assert np.all(offs[26:] == 0)                                        # time-recurrent block not exported by default
+    offs = offs[:26]
     assert np.all(offs % 4 == 0) and np.all(np.diff(offs) > 0)          # 16-byte aligned sections, in kernel order
     assert len(blob) >= offs[-1] + 8 * 8 * 5 + 8 + 64 * 256               # fixed-size requests never leave the blob
     o_first, o_pw, o_dw = offs[0], offs[1:6], offs[6:11]
@@ -146,8 +148,66 @@ def test_recurrence_weights_are_in_thread_order():
                                    bb.detach().double().numpy(), rtol=1e-6, atol=1e-7)
 
 
+def test_tgru_sections_of_the_streaming_artefact():
+    """fold(net, tgru=True): the time-recurrent block of network.py:150 as 16-row tiles -- r and z rows over the
+    concatenated K = [x (64) | h (128)] with b_ih + b_hh, the n rows of W_ih and of W_hh apart (r multiplies W_hn h + b_hn
+    only), TGRU.conv with its BatchNorm folded"""
+    net = _net()
+    blob, offs, _ = export.fold(net, tgru=True)
+    assert len(offs) == 30 and np.all(offs[26:] > 0) and np.all(np.diff(offs) > 0) and np.all(offs % 4 == 0)
+    o_rz, o_in, o_hn, o_cv = (int(v) for v in offs[26:])
+    g = net.TGRU.GRU
+    Wih, Whh = g.weight_ih_l0.detach().double().numpy(), g.weight_hh_l0.detach().double().numpy()
+    bih, bhh = g.bias_ih_l0.detach().double().numpy(), g.bias_hh_l0.detach().double().numpy()
+    W, b = _decode16(blob[o_rz:o_in].astype(np.float64), 256, 192)
+    np.testing.assert_allclose(W, np.concatenate([Wih[:256], Whh[:256]], 1), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(b, bih[:256] + bhh[:256], rtol=1e-6, atol=1e-7)
+    W, b = _decode16(blob[o_in:o_hn].astype(np.float64), 128, 64)
+    np.testing.assert_allclose(W, Wih[256:], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(b, bih[256:], rtol=1e-6, atol=1e-7)
+    W, b = _decode16(blob[o_hn:o_cv].astype(np.float64), 128, 128)
+    np.testing.assert_allclose(W, Whh[256:], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(b, bhh[256:], rtol=1e-6, atol=1e-7)
+    tc, tbn = net.TGRU.conv[0], net.TGRU.conv[1]
+    Wr, br = _fold_conv_bn(tc.weight.detach()[:, :, 0], tc.bias.detach(), tbn)
+    W, b = _decode16(blob[o_cv:o_cv + 4 * 9 * 256].astype(np.float64), 64, 128)
+    np.testing.assert_allclose(W, Wr, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(b, br, rtol=1e-6, atol=1e-7)
+
+
+def test_section_bounds_check_refuses_truncated_and_foreign_images():
+    """the offsets of an artefact are checked against the blob length (host side, no GPU): a truncated blob, an
+    offset past the end, a misaligned or negative offset, a wrong C_in or a TGRU state request without the block are
+    TRUNET_EINVAL, not a GPU fault"""
+    import ctypes as C
+    net = _net()
+    lib = L.lib()
+
+    def check(blob, offs, cin):
+        arr = (C.c_int32 * len(offs))(*[int(v) for v in offs])
+        return lib.trunet_stream_fwd_check(arr, len(offs), len(blob), cin)
+    for tg in (False, True):
+        blob, offs, cin = export.fold(net, tgru=tg)
+        assert check(blob, offs, cin) == L.TRUNET_OK
+        assert check(blob[:len(blob) - 20000], offs, cin) == L.TRUNET_EINVAL          # truncated
+        assert check(blob[:int(offs[20])], offs, cin) == L.TRUNET_EINVAL
+        bad = offs.copy(); bad[7] = len(blob) + 4
+        assert check(blob, bad, cin) == L.TRUNET_EINVAL                               # section past the end
+        bad = offs.copy(); bad[3] += 2
+        assert check(blob, bad, cin) == L.TRUNET_EINVAL                               # not 16-byte aligned
+        bad = offs.copy(); bad[0] = -4
+        assert check(blob, bad, cin) == L.TRUNET_EINVAL
+        assert check(blob, offs[:26], cin) == L.TRUNET_EINVAL                         # the 26-offset v2 layout
+        assert check(blob, offs, 5) == L.TRUNET_EINVAL
+    blob, offs, cin = export.fold(net)
+    bad = offs.copy(); bad[28] = 64                                                   # partial TGRU export
+    assert check(blob, bad, cin) == L.TRUNET_EINVAL
+    with pytest.raises(L.TrunetHipError):
+        export.FoldedTRUNet(blob[:1000], offs, cin, device="cpu")
+
+
 def test_artefact_of_another_format_is_refused(tmp_path):
     p = tmp_path / "old.pt"
-    torch.save({"format": "trunet-folded-v1", "blob": torch.zeros(8), "offsets": torch.zeros(26, dtype=torch.int32), "cin": 4}, p)
+    torch.save({"format": "trunet-folded-v2", "blob": torch.zeros(8), "offsets": torch.zeros(26, dtype=torch.int32), "cin": 4}, p)
     with pytest.raises(L.TrunetHipError):
         export.FoldedTRUNet.load(str(p))

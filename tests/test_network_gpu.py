@@ -323,28 +323,67 @@ def test_saved_activations_are_guarded():
     (y2 * cot).sum().backward()                # the most recent forward is intact
 
 
-def test_tgru_streaming_matches_oracle():
-    """Stateful streaming with the TGRU block: five consecutive frames of 37 streams, hidden state
-    carried, vs the fp64 oracle's nn.GRU stepping (build-defined path: the reference never calls TGRU)."""
+@pytest.mark.parametrize("path", ["folded", "layers"])
+@pytest.mark.parametrize("streams", [37, 300])
+def test_tgru_streaming_matches_oracle(path, streams):
+    """Stateful streaming with the TGRU block (network.py:150, rt.py:20-27): consecutive frames of
+    `streams` streams, hidden state carried, vs the fp64 oracle's nn.GRU stepping (build-defined path: the reference never
+    calls TGRU).  "folded": the whole step incl. the GRU time step in ONE launch (export.fold(tgru=True),
+    stream_fwd_kernel<true>; 300 streams = more frames than workgroups, so a workgroup carries several streams);
+    "layers": the layer-by-layer kernels (fold_eval = False)."""
     from oracle import network_ref as nr, weights as W
     ref, net = _nets(4, seed=7)
     refd = W.fill_state_dict(nr.TRUNet(input_size=4), seed=7).double().eval()
     net.eval()
+    net.fold_eval = path == "folded"
     rng = np.random.default_rng(5)
     h, state = None, None
     for t in range(5):
-        x = torch.tensor(rng.standard_normal((37, 4, 257)) * 0.5, dtype=torch.float32)
+        x = torch.tensor(rng.standard_normal((streams, 4, 257)) * 0.5, dtype=torch.float32)
         with torch.no_grad():
             yd, h = refd.stream_step(x.double(), h)
         y, state = net.stream_step(x.cuda(), state)
         assert _rel(y, yd) < 1e-4, (t, _rel(y, yd))
-    assert state.steps == 5
-    # hidden state parity: oracle h is (1, S*16, 128) with row s*16 + l; ours [128][16][NP]
-    hh = state.h[:, :, :37].permute(2, 1, 0).reshape(37 * 16, 128)
+    assert state.steps == 5 and state.layout == ("folded" if path == "folded" else "frames_last")
+    # hidden state parity: oracle h is (1, S*16, 128) with row s*16 + l
+    hh = state.hidden().reshape(streams * 16, 128)
     assert _rel(hh, h[0]) < 1e-4
+    with pytest.raises(Exception):
+        net.stream_step(x.cuda()[:5], state)            # a state belongs to its number of streams
     with pytest.raises(Exception):
         net.train()
         net.stream_step(x.cuda(), state)
+
+
+def test_folded_stream_step_replays_from_a_hip_graph():
+    """the state keeps its address and is updated in place, so one captured step replays frame after frame
+    (bench.py --streaming --tgru)"""
+    from oracle import network_ref as nr, weights as W
+    ref, net = _nets(4, seed=8)
+    refd = W.fill_state_dict(nr.TRUNet(input_size=4), seed=8).double().eval()
+    net.eval()
+    rng = np.random.default_rng(6)
+    xs = [torch.tensor(rng.standard_normal((64, 4, 257)) * 0.5, dtype=torch.float32) for _ in range(4)]
+    xg = xs[0].cuda()
+    y, state = net.stream_step(xg, None)                # frame 0 eagerly (builds the artefact and the state)
+    with torch.no_grad():
+        yd, h = refd.stream_step(xs[0].double(), None)
+    assert _rel(y, yd) < 1e-4
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    keep = state.h.clone()
+    with torch.cuda.graph(g):
+        yg, _ = net.stream_step(xg, state)
+    state.h.copy_(keep)                                  # capture does not execute; make sure of the starting state
+    state.steps = 1
+    for t in range(1, 4):
+        xg.copy_(xs[t].cuda())
+        g.replay()
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            yd, h = refd.stream_step(xs[t].double(), h)
+        assert _rel(yg, yd) < 1e-4, t
+    assert _rel(state.hidden().reshape(64 * 16, 128), h[0]) < 1e-4
 
 
 @pytest.mark.parametrize("B,T", [(3, 7), (2, 40)])

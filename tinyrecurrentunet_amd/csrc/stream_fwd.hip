@@ -363,8 +363,10 @@ __device__ __forceinline__ void sf_restore(float* lds, int buf, int ls, const fl
 
 struct SfArgs {
     const float* x; float* y; const float* blob; float* scratch;
+    const float* h_in; float* h_out;            // TG: hidden state of the time-recurrent block, (streams, 128, 16) each
     int N, Cin;
     int o_first, o_pw[5], o_dw[5], o_gi, o_whh, o_fg, o_dpw[6], o_ct[5], o_last;
+    int o_tg_rz, o_tg_in, o_tg_hn, o_tg_conv;
 };
 
 #define SF_SYNC() __syncthreads()
@@ -389,6 +391,10 @@ struct SfArgs {
 constexpr int LSA = sf_ls(128);          // one row stride (144 floats) for every activation buffer: immediate LDS offsets
 constexpr int LSG = sf_ls(16);           // ... except the GRU projection [384][32]
 
+// TG: with the time-recurrent block (network.py:150; GRUBlock :45-58) between FGRU.conv and decoder.0: one GRU time step per
+// (stream, frequency position), hidden state (128 x 16 per stream) read from / written to HBM.  Its own instance, so that
+// the stateless kernel's code footprint (instruction cache) stays what it was.
+template <bool TG>
 __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -630,9 +636,76 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
             SF_STAMP(8);
             // FGRU.conv (128 -> 64) + BN + ReLU
             SF_TAKE(9);
-            SF_REQUEST(5, A.o_dpw[0], wave);                                  // decoder.0 pw: 64 -> 64
+            if constexpr (TG) SF_REQUEST(13, A.o_tg_rz, wave);                // TGRU r/z rows, first pass
+            else SF_REQUEST(5, A.o_dpw[0], wave);                             // decoder.0 pw: 64 -> 64
             sf_pw16<32, 0, 1, false, true>(fs, lds, SF_R0, LSA, 0, 0, 0, SF_R1A, LSA, 16, 64);
             sf_guards(lds, SF_R1A, 64, LSA, 16);
+            if constexpr (TG) {
+                // ---------------- TGRU (network.py:150): x = R1A (64 x 16); h_{t-1} of this stream -> R1B as [128][LSG]
+                sf_restore(lds, SF_R1B, LSG, A.h_in + (size_t)n * 2048, 128, 2);
+                SF_SYNC();
+                // r and z rows: W_ih x + W_hh h + (b_ih + b_hh) as ONE K = 64 + 128 GEMM, sixteen 16-row tiles in four
+                // passes of one tile per wave -> R0 rows [0, 256) (stride LSG); n rows: W_in x + b_in -> rows [256, 384),
+                // W_hn h + b_hn -> rows [384, 512) (kept apart: r multiplies the latter only), two passes of 1 + 1 tiles
+                for (int ps = 0; ps < 4; ++ps) {
+                    SF_TAKE(13);
+                    {
+                        // next r/z pass, or the first n pass: W_in tile (5 quads) + W_hn tile (9 quads) requested as 5 + 9
+                        const int off_ = ps < 3 ? A.o_tg_rz + (4 * (ps + 1) + wave) * 3328 : A.o_tg_in + wave * 1280;
+                        SF_REQUEST(5, off_, 0);
+                        const int off2_ = ps < 3 ? off_ + 1280 : A.o_tg_hn + wave * 2304;
+                        sf_load<9>(fp + 20, blob + off2_, lane);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    sf_pw16<16, 32, 1, false, true, false>(fs, lds, SF_R1A, LSA, 0, SF_R1B, LSG, SF_R0, LSG, 16, 512, nullptr,
+                                                           16 * (4 * ps + wave));
+                }
+                for (int ps = 0; ps < 2; ++ps) {
+                    SF_TAKE(14);
+                    {
+                        const int off_ = ps < 1 ? A.o_tg_in + (4 + wave) * 1280 : A.o_tg_conv + wave * 2304;
+                        SF_REQUEST(5, off_, 0);
+                        const int off2_ = ps < 1 ? A.o_tg_hn + (4 + wave) * 2304 : A.o_tg_conv + wave * 2304 + 1280;
+                        sf_load<9>(fp + 20, blob + off2_, lane);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    sf_pw16<16, 0, 1, false, true, false>(fs, lds, SF_R1A, LSA, 0, 0, 0, SF_R0, LSG, 16, 512, nullptr,
+                                                          256 + 16 * (4 * ps + wave));
+                    sf_pw16<32, 0, 1, false, true, false>(fs + 20, lds, SF_R1B, LSG, 0, 0, 0, SF_R0, LSG, 16, 512, nullptr,
+                                                          384 + 16 * (4 * ps + wave));
+                }
+                SF_SYNC();
+                {
+                    // gates (torch.nn.GRU order r, z, n): thread = (hidden unit u, 8 of the 16 positions)
+                    const int t_ = sf_tid();
+                    const int u = t_ >> 1, p0 = 8 * (t_ & 1);
+                    const float* gr = lds + SF_R0 + u * LSG + 4 + p0;
+                    float* hp = lds + SF_R1B + u * LSG + 4 + p0;
+                    float* hg = A.h_out + (size_t)n * 2048 + u * 16 + p0;
+#pragma unroll
+                    for (int q4 = 0; q4 < 2; ++q4) {
+                        const f32x4 ar = *(const f32x4*)(gr + 4 * q4), az = *(const f32x4*)(gr + 128 * LSG + 4 * q4);
+                        const f32x4 an = *(const f32x4*)(gr + 256 * LSG + 4 * q4), ah = *(const f32x4*)(gr + 384 * LSG + 4 * q4);
+                        const f32x4 hv = *(const f32x4*)(hp + 4 * q4);
+                        f32x4 ho;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float r = sf_sigmoid(ar[e]);
+                            const float z = sf_sigmoid(az[e]);
+                            const float nn = sf_tanh(fmaf(r, ah[e], an[e]));
+                            ho[e] = (1.f - z) * nn + z * hv[e];
+                        }
+                        *(f32x4*)(hp + 4 * q4) = ho;
+                        *(f32x4*)(hg + 4 * q4) = ho;
+                    }
+                }
+                SF_SYNC();
+                // TGRU.conv (128 -> 64) + BN + ReLU on h_t -> R1A (the decoder's input, as without the block)
+                SF_TAKE(9);
+                SF_REQUEST(5, A.o_dpw[0], wave);                              // decoder.0 pw: 64 -> 64
+                sf_pw16<32, 0, 1, false, true>(fs, lds, SF_R1B, LSG, 0, 0, 0, SF_R1A, LSA, 16, 64);
+                sf_guards(lds, SF_R1A, 64, LSA, 16);
+            }
             SF_SYNC();
             // ---------------- decoder.0 (FirstTrCNN): pw 64 -> 64, ConvT k3 s2 -> L 31            network.py:60-76
             SF_TAKE(5);
@@ -753,13 +826,51 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
 extern "C" size_t trunet_stream_fwd_scratch_floats(int grid) { return (size_t)grid * SF_SKIP + 256; }
 extern "C" int trunet_stream_fwd_grid(int N) { return N < 2 * TRUNET_NUM_CU ? (N < TRUNET_NUM_CU ? N : TRUNET_NUM_CU) : TRUNET_NUM_CU; }
 
+// Every section of the exported image must lie inside the blob, fragment over-reads (the kernel requests fixed-size blocks
+// of up to 21 quads per wave) included: a truncated or foreign artefact is refused here instead of faulting on the GPU.
+extern "C" int trunet_stream_fwd_check(const int32_t* h_offsets, int n_offsets, int64_t blob_numel, int Cin) {
+    if (!h_offsets || n_offsets != 30 || (Cin != 3 && Cin != 4) || blob_numel <= 0) return TRUNET_EINVAL;
+    const int64_t T32 = 256;           // floats per quad of a tile
+    int64_t size[30];
+    int i = 0;
+    size[i++] = 64 * Cin * 5 + 64;                                     // first conv
+    size[i++] = 4 * 12 * T32;                                          // encoder.1 pw (K = 64, 32-row tiles)
+    for (int k = 0; k < 4; ++k) size[i++] = 4 * 20 * T32;              // encoder.2..5 pw (K = 128)
+    { const int ks[5] = {3, 5, 3, 5, 3}; for (int k = 0; k < 5; ++k) size[i++] = 128 * ks[k] + 128; }
+    size[i++] = 24 * 9 * T32;                                          // FGRU input projection (384 x 128, 16-row tiles)
+    size[i++] = 2 * 24 * 128 * 4 + 384;                                // W_hh, b_hh
+    size[i++] = 4 * 9 * T32;                                           // FGRU.conv
+    size[i++] = 4 * 5 * T32;                                           // decoder.0 pw
+    for (int k = 0; k < 4; ++k) size[i++] = 4 * 13 * T32;              // decoder.1..4 pw (K = 192)
+    size[i++] = 1 * 9 * T32;                                           // decoder.5 pw (8 rows)
+    { const int taps[5] = {3, 5, 3, 5, 3}; for (int k = 0; k < 5; ++k) size[i++] = 4 * (4 * taps[k] + 1) * T32; }
+    size[i++] = 8 * 8 * 5 + 8;                                         // last ConvT
+    size[i++] = 16 * 13 * T32; size[i++] = 8 * 5 * T32; size[i++] = 8 * 9 * T32; size[i++] = 4 * 9 * T32;   // TGRU
+    const bool tg = h_offsets[26] > 0;
+    for (int k = 0; k < 30; ++k) {
+        if (k >= 26 && !tg) { if (h_offsets[k] != 0) return TRUNET_EINVAL; continue; }
+        const int64_t o = h_offsets[k];
+        if (o < 0 || (o & 3)) return TRUNET_EINVAL;
+        if (k >= 26 && o == 0) return TRUNET_EINVAL;
+        if (o + size[k] + 21 * T32 > blob_numel) return TRUNET_EINVAL;
+    }
+    return TRUNET_OK;
+}
+
 extern "C" int trunet_stream_fwd(const float* x, float* y, const float* blob, const int32_t* h_offsets, int n_offsets,
-                                 float* scratch, int N, int Cin, void* stream) {
+                                 int64_t blob_numel, float* scratch, const float* h_in, float* h_out, int N, int Cin,
+                                 void* stream) {
     if (!x || !y || !blob || !h_offsets || !scratch || N <= 0) return TRUNET_EINVAL;
     if (Cin != 3 && Cin != 4) return TRUNET_ENOTSUP;
-    if (n_offsets != 26) return TRUNET_EINVAL;
+    if ((h_in == nullptr) != (h_out == nullptr)) return TRUNET_EINVAL;
+    {
+        const int rc = trunet_stream_fwd_check(h_offsets, n_offsets, blob_numel, Cin);
+        if (rc != TRUNET_OK) return rc;
+    }
+    const bool tg = h_in != nullptr;
+    if (tg && h_offsets[26] <= 0) return TRUNET_EINVAL;          // state given, block not exported
     SfArgs a;
-    a.x = x; a.y = y; a.blob = blob; a.scratch = scratch; a.N = N; a.Cin = Cin;
+    a.x = x; a.y = y; a.blob = blob; a.scratch = scratch; a.h_in = h_in; a.h_out = h_out; a.N = N; a.Cin = Cin;
     int i = 0;
     a.o_first = h_offsets[i++];
     for (int k = 0; k < 5; ++k) a.o_pw[k] = h_offsets[i++];
@@ -768,11 +879,17 @@ extern "C" int trunet_stream_fwd(const float* x, float* y, const float* blob, co
     for (int k = 0; k < 6; ++k) a.o_dpw[k] = h_offsets[i++];
     for (int k = 0; k < 5; ++k) a.o_ct[k] = h_offsets[i++];
     a.o_last = h_offsets[i++];
-    for (int k = 0; k < 26; ++k) if (h_offsets[k] < 0 || (h_offsets[k] & 3)) return TRUNET_EINVAL;
+    a.o_tg_rz = h_offsets[i++]; a.o_tg_in = h_offsets[i++]; a.o_tg_hn = h_offsets[i++]; a.o_tg_conv = h_offsets[i++];
     const int grid = trunet_stream_fwd_grid(N);
     const size_t ldsb = (size_t)SF_ARENA * sizeof(float);
-    if (hipFuncSetAttribute((const void*)stream_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess)
-        return TRUNET_ELAUNCH;
-    hipLaunchKernelGGL(stream_fwd_kernel, dim3(grid), dim3(SF_T), ldsb, (hipStream_t)stream, a);
+    if (tg) {
+        if (hipFuncSetAttribute((const void*)stream_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess)
+            return TRUNET_ELAUNCH;
+        hipLaunchKernelGGL(stream_fwd_kernel<true>, dim3(grid), dim3(SF_T), ldsb, (hipStream_t)stream, a);
+    } else {
+        if (hipFuncSetAttribute((const void*)stream_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess)
+            return TRUNET_ELAUNCH;
+        hipLaunchKernelGGL(stream_fwd_kernel<false>, dim3(grid), dim3(SF_T), ldsb, (hipStream_t)stream, a);
+    }
     return trunet_launch_status();
 }

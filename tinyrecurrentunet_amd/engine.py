@@ -643,11 +643,13 @@ class TRUNetEngine:
         Hh, Lg = gru.hidden_size, cur.L
         if gru.bidirectional or gru.input_size != cur.C:
             raise L.TrunetHipError("TGRU streaming expects the unidirectional GRUBlock(64, 128, 64) of network.py:150")
+        if state.h is not None and state.n != N:
+            raise L.TrunetHipError("stream state belongs to %d streams, got %d" % (state.n, N))
         if state.h is None or tuple(state.h.shape) != (Hh, Lg, NP):
             state.h = torch.zeros((Hh, Lg, NP), device=cur.t.device, dtype=torch.float32)     # h0 = 0 like nn.GRU
             state.n = N
-        if state.n != N:
-            raise L.TrunetHipError("stream state belongs to %d streams, got %d" % (state.n, N))
+            if getattr(state, "layout", None) is None:
+                state.layout = "frames_last"
         gi = w.get("tgru.gi", (3 * Hh, Lg, NP))
         gh = w.get("tgru.gh", (3 * Hh, Lg, NP))
         self._gemm(w, N=N, NP=NP, P=Lg, M=3 * Hh, out=gi, out_L=Lg, W=gru.weight_ih_l0.data, ldw_m=gru.input_size,

@@ -7,7 +7,12 @@ weight tiles in MFMA fragment order -- 32-row tiles (v_mfma_f32_32x32x2_f32: A f
 the 128-channel encoder layers, 16-row tiles (v_mfma_f32_16x16x4_f32: A fragments then 4 bias values) for the GRU
 projection, FGRU.conv and every decoder layer -- and per-tap matrices for the transposed convs.  The artefact is ONE flat fp32 tensor + 26 offsets; ``FoldedTRUNet.save`` / ``load`` store it with
 ``torch.save`` and read it back with ``weights_only=True``.  ``FoldedTRUNet.forward(x)`` is the whole network in one
-kernel launch: (N, C_in, 257) -> (N, 8, 257), every frame independent (the reference's forward without TGRU, R4)."""
+kernel launch: (N, C_in, 257) -> (N, 8, 257), every frame independent (the reference's forward without TGRU, R4).
+
+Round 3: ``fold(net, tgru=True)`` also exports the time-recurrent block (network.py:150, GRUBlock :45-58) for the stateful
+causal stream of rt.py:20-27 / stream.py:83-109: ``FoldedTRUNet.stream_step(x, h)`` advances every (stream, frequency
+position) sequence by ONE GRU time step inside the same single launch (between FGRU.conv and decoder.0, as drawn in
+docs/net.jpg); the hidden state h (streams, 128, 16) lives in HBM, 8 KB per stream, read and written by the kernel."""
 import ctypes as C
 
 import numpy as np
@@ -71,8 +76,14 @@ def _frag_tiles16(Wm, bias):
     return np.concatenate(out)
 
 
-def fold(net):
-    """TRUNet (network.py R1 layer sizes) -> (blob float32 ndarray, offsets int32[26], C_in)"""
+N_OFFSETS = 30          # 26 sections of the stateless forward + 4 of the time-recurrent block (0 when not exported)
+
+
+def fold(net, tgru=False):
+    """TRUNet (network.py R1 layer sizes) -> (blob float32 ndarray, offsets int32[30], C_in).  Offsets 26..29 are the
+    TGRU sections (0 = not exported): [W_ih | W_hh] rows of the r and z gates as sixteen 16-row tiles over K = 64 + 128
+    (bias b_ih + b_hh), W_ih rows of the n gate (8 tiles, K = 64, bias b_in), W_hh rows of the n gate (8 tiles, K = 128,
+    bias b_hn: it sits inside r * (.)), TGRU.conv + BatchNorm folded (4 tiles, K = 128)."""
     sec, offs = [], []
 
     def add(arr):
@@ -138,6 +149,21 @@ def fold(net):
         add(a)                                                                         # o_ct[5]
     add(last)                                                                          # o_last
     assert len(offs) == 26
+    if tgru:
+        tg = net.TGRU.GRU
+        if tg.bidirectional or tg.input_size != 64 or tg.hidden_size != 128:
+            raise L.TrunetHipError("the exported time-recurrent block is the GRUBlock(64, 128, 64) of network.py:150")
+        Wih, Whh, bih, bhh = t(tg.weight_ih_l0), t(tg.weight_hh_l0), t(tg.bias_ih_l0), t(tg.bias_hh_l0)
+        H = 128
+        add(_frag_tiles16(np.concatenate([Wih[:2 * H], Whh[:2 * H]], 1), bih[:2 * H] + bhh[:2 * H]))    # o_tg_rz
+        add(_frag_tiles16(Wih[2 * H:], bih[2 * H:]))                                                    # o_tg_in
+        add(_frag_tiles16(Whh[2 * H:], bhh[2 * H:]))                                                    # o_tg_hn
+        sc, sh = _bn_affine(net.TGRU.conv[1])
+        tc = net.TGRU.conv[0]
+        add(_frag_tiles16(t(tc.weight)[:, :, 0] * sc.numpy()[:, None], t(tc.bias) * sc.numpy() + sh.numpy()))   # o_tg_conv
+    else:
+        offs.extend([0, 0, 0, 0])
+    assert len(offs) == N_OFFSETS
     sec.append(np.zeros(64 * 256))         # the kernel requests fixed-size fragment blocks: over-reads stay inside the blob
     return np.concatenate(sec).astype(np.float32), np.array(offs, dtype=np.int32), cin
 
@@ -146,31 +172,42 @@ class FoldedTRUNet:
     """The exported inference artefact and its runner (one kernel launch per forward)."""
 
     def __init__(self, blob, offsets, cin, device=None):
+        blob = torch.as_tensor(blob, dtype=torch.float32)
+        offsets = np.ascontiguousarray(np.asarray(offsets, dtype=np.int32))
+        if blob.dim() != 1 or offsets.shape != (N_OFFSETS,) or int(cin) not in (3, 4):
+            raise L.TrunetHipError("not a folded TRU-Net image: blob %s, %s offsets, cin %r" % (
+                tuple(blob.shape), offsets.shape, cin))
+        # host-side twin of the entry point's bounds check: a truncated or foreign artefact must not reach the kernel
+        rc = L.lib().trunet_stream_fwd_check(offsets.ctypes.data_as(C.POINTER(C.c_int32)), len(offsets), blob.numel(),
+                                             int(cin))
+        if rc != L.TRUNET_OK:
+            raise L.TrunetHipError("folded TRU-Net image fails the section bounds check (truncated or foreign artefact)")
         dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-        self.blob = torch.as_tensor(blob, dtype=torch.float32).to(dev).contiguous()
-        self.offsets = np.ascontiguousarray(np.asarray(offsets, dtype=np.int32))
+        self.blob = blob.to(dev).contiguous()
+        self.offsets = offsets
         self._offs = (C.c_int32 * len(self.offsets))(*[int(v) for v in self.offsets])
         self.cin = int(cin)
+        self.has_tgru = bool(offsets[26] > 0)
         self._scratch = None
 
     @classmethod
-    def from_module(cls, net, device=None):
-        blob, offs, cin = fold(net)
+    def from_module(cls, net, device=None, tgru=False):
+        blob, offs, cin = fold(net, tgru=tgru)
         dev = device if device is not None else next(net.parameters()).device
         return cls(blob, offs, cin, dev)
 
     def save(self, path):
-        torch.save({"format": "trunet-folded-v2", "blob": self.blob.cpu(), "offsets": torch.tensor(self.offsets),
+        torch.save({"format": "trunet-folded-v3", "blob": self.blob.cpu(), "offsets": torch.tensor(self.offsets),
                     "cin": self.cin}, path)
 
     @classmethod
     def load(cls, path, device=None):
         d = torch.load(path, map_location="cpu", weights_only=True)
-        if d.get("format") != "trunet-folded-v2":
-            raise L.TrunetHipError("%s is not a folded TRU-Net artefact" % path)
+        if d.get("format") != "trunet-folded-v3":
+            raise L.TrunetHipError("%s is not a folded TRU-Net artefact (format %r)" % (path, d.get("format")))
         return cls(d["blob"], d["offsets"].numpy(), int(d["cin"]), device)
 
-    def forward(self, x):
+    def _run(self, x, h_in, h_out):
         if not x.is_cuda:
             raise L.TrunetHipError("tinyrecurrentunet_amd runs on MI355X only: got a %s tensor" % x.device)
         x = x.contiguous().float()
@@ -182,8 +219,26 @@ class FoldedTRUNet:
         if self._scratch is None or self._scratch.numel() < need or self._scratch.device != x.device:
             self._scratch = torch.empty(need, device=x.device, dtype=torch.float32)
         y = torch.empty((N, 8, 257), device=x.device, dtype=torch.float32)
-        check(lib.trunet_stream_fwd(ptr(x), ptr(y), ptr(self.blob), self._offs, len(self.offsets), ptr(self._scratch), N,
-                                    self.cin, L.stream()), "stream_fwd")
+        check(lib.trunet_stream_fwd(ptr(x), ptr(y), ptr(self.blob), self._offs, len(self.offsets), self.blob.numel(),
+                                    ptr(self._scratch), ptr(h_in), ptr(h_out), N, self.cin, L.stream()), "stream_fwd")
         return y
 
+    def forward(self, x):
+        return self._run(x, None, None)
+
     __call__ = forward
+
+    def new_state(self, streams, device=None):
+        """h0 = 0 like nn.GRU: (streams, 128 hidden units, 16 frequency positions) fp32"""
+        dev = device if device is not None else self.blob.device
+        return torch.zeros((streams, 128, 16), device=dev, dtype=torch.float32)
+
+    def stream_step(self, x, h):
+        """One new STFT frame per stream, time-recurrent block included: x (streams, C_in, 257), h the state of
+        ``new_state`` -- updated IN PLACE (every (stream, unit, position) element is read and written by the same thread
+        of the same workgroup), so the state keeps its address and a captured hipGraph replays frame after frame."""
+        if not self.has_tgru:
+            raise L.TrunetHipError("this artefact was exported without the time-recurrent block: fold(net, tgru=True)")
+        if h.shape != (x.shape[0], 128, 16) or h.dtype != torch.float32 or not h.is_cuda or not h.is_contiguous():
+            raise ValueError("state must be the contiguous fp32 (streams, 128, 16) tensor of new_state()")
+        return self._run(x, h, h)

@@ -246,10 +246,24 @@ class TRUNet(nn.Module):
             raise _lib.TrunetHipError("stream_step is an inference path: call net.eval() first")
         if self.precision != "fp32":
             raise _lib.TrunetHipError("stream_step is fp32 only")
-        if self._engine is None:
-            object.__setattr__(self, "_engine", TRUNetEngine(self))
         if state is None:
             state = TRUNetStreamState()
+        if state.layout is None:
+            state.layout = "folded" if (self.fold_eval and 0 < x.shape[0] <= self.fold_max_frames) else "frames_last"
+        if state.layout == "folded":
+            # the whole step -- encoder, FGRU, ONE TGRU time step per (stream, frequency position), decoder -- in ONE launch
+            # (export.fold(tgru=True) + stream_fwd_kernel<true>); the state (streams, 128, 16) is updated in place
+            run = self.folded(tgru=True)
+            if state.h is None:
+                state.h, state.n = run.new_state(x.shape[0], x.device), x.shape[0]
+            if state.n != x.shape[0]:
+                raise _lib.TrunetHipError("stream state belongs to %d streams, got %d" % (state.n, x.shape[0]))
+            with torch.no_grad():
+                out = run.stream_step(x, state.h)
+            state.steps += 1
+            return out, state
+        if self._engine is None:
+            object.__setattr__(self, "_engine", TRUNetEngine(self))
         with torch.no_grad():
             out, _ = self._engine.forward(x.float(), False, tgru_state=state)
         return out, state
@@ -281,27 +295,41 @@ class TRUNet(nn.Module):
     fold_eval = True
     fold_max_frames = 8192
 
-    def folded(self):
+    def folded(self, tgru=False):
         """The exported inference artefact of the current weights (export.FoldedTRUNet), rebuilt when a parameter or
-        buffer has been modified since (tensor version counters)."""
+        buffer has been modified since; tgru=True: with the time-recurrent block (the stateful stream_step artefact)."""
         from .export import FoldedTRUNet
-        ts = [t for n, t in self.state_dict(keep_vars=True).items() if not n.startswith("TGRU.")]
+        ts = [t for n, t in self.state_dict(keep_vars=True).items() if tgru or not n.startswith("TGRU.")]
         # version counters catch torch-side writes (load_state_dict, in-place ops); the mutation epoch catches the
         # product's own raw-pointer writers (FusedAdamW.step, the BatchNorm running statistics of a training forward)
         key = (tuple(t._version for t in ts), tuple(t.data_ptr() for t in ts[:2]), str(ts[0].device),
                _lib.mutation_epoch())
-        cached = self.__dict__.get("_folded_cache")
+        cache = self.__dict__.get("_folded_cache")
+        if cache is None:
+            cache = {}
+            object.__setattr__(self, "_folded_cache", cache)
+        cached = cache.get(bool(tgru))
         if cached is None or cached[0] != key:
-            cached = (key, FoldedTRUNet.from_module(self))
-            object.__setattr__(self, "_folded_cache", cached)
+            cached = (key, FoldedTRUNet.from_module(self, tgru=tgru))
+            cache[bool(tgru)] = cached
         return cached[1]
 
 
 class TRUNetStreamState:
-    """Hidden state of the TGRU block for ``TRUNet.stream_step``: h [128][16][NP] (frames-last), one column per stream."""
+    """Hidden state of the TGRU block for ``TRUNet.stream_step``: one 128-vector per (stream, frequency position).
+    layout "folded" (the single-launch path): h (streams, 128, 16); layout "frames_last" (the layer-by-layer kernels, more
+    than ``fold_max_frames`` streams or ``fold_eval = False``): h [128][16][NP], one column per stream."""
 
-    def __init__(self):
-        self.h, self.n, self.steps = None, 0, 0
+    def __init__(self, layout=None):
+        self.h, self.n, self.steps, self.layout = None, 0, 0, layout
+
+    def hidden(self):
+        """(streams, 16, 128) view of the state, whatever the layout"""
+        if self.h is None:
+            return None
+        if self.layout == "folded":
+            return self.h.permute(0, 2, 1)
+        return self.h[:, :, :self.n].permute(2, 1, 0)
 
 
 # train.py:22 imports this name (it does not exist in the reference either, SURVEY D12): alias only.
