@@ -835,8 +835,11 @@ class TRUNetEngine:
                 d.flags = fl
             if PROFILE is not None:
                 fl_ = 4.0 * N * M * sum(s.nchan * _seg_positions(s, 0, P) for s in segs)
+                # the instance trunet_pw_bwd launches, as rocprofv3 prints it: <AK, SEC, KSPLIT> (KSPLIT: two source row tiles)
+                ksplit = K == 64 and os.environ.get("TRUNET_PWB_KSPLIT", "1") != "0"
                 name = "pw_bwd_small_kernel" if M <= 8 else \
-                    "pw_bwd_kernel<%d, %s>" % (32 if M <= 64 else 64, "true" if K == 192 else "false")
+                    "pw_bwd_kernel<%d, %s, %s>" % (32 if M <= 64 else 64, "true" if K == 192 else "false",
+                                                   "true" if ksplit else "false")
                 with _Timed(name, fl_, "M%d K%s P%d" % (M, "+".join(str(s.nchan) for s in segs), P)):
                     rc = lib.trunet_pw_bwd(a, L.stream())
             else:
