@@ -261,6 +261,14 @@ def test_block_backward_vs_oracle_f64_at_8200_frames(name):
     _block_vs_f64(name, 8200, ptol=2e-3, zero_floor=2e-2 * (8200 / 777.0) ** 0.5)
 
 
+@pytest.mark.parametrize("N", [1000, 8448])
+def test_first_conv_backward_vs_oracle_f64_on_256_frame_chunks(N):
+    """StandardConv1d (network.py:9-21) at frame counts whose padded size is a multiple of 256: the weight gradient runs on
+    wgrad_first_kernel (round 3: one wave per SIMD, dz rows double-buffered in registers, x rows refilled per channel)
+    instead of wgrad_small_kernel<4, 4, 5>; ragged N (frames >= N in the last chunk are zeroed), several items per block"""
+    _block_vs_f64("std", N, ptol=1e-3 if N < 2000 else 2e-3)
+
+
 def _block_vs_f64(name, N, ptol=1e-3, zero_floor=2e-2):
     from oracle import network_ref as nr, weights as W
     from tinyrecurrentunet_amd import network as hn

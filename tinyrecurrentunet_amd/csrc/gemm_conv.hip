@@ -504,6 +504,15 @@ int launch_gemm(const trunet_gemm_args* h, int NB, size_t lds, hipStream_t st, i
 
 template <int RS>
 int launch_gemm_rs(const trunet_gemm_args* h, int kc, bool two, int epl, int NB, size_t lds, hipStream_t st, int nw) {
+    if constexpr (RS == 2) {
+        // K <= 8 rows of dz (the data gradient of decoder.5's 128 -> 8 pointwise layer): 8-row chunks -- a 32-row chunk
+        // moved and multiplied 24 rows of padding per tile
+        if (two && kc == 8) {
+            if (epl == 0) return launch_gemm<RS, 8, true, 0>(h, NB, lds, st, nw);
+            if (epl == 1) return launch_gemm<RS, 8, true, 1>(h, NB, lds, st, nw);
+            return launch_gemm<RS, 8, true, 2>(h, NB, lds, st, nw);
+        }
+    }
     if (two && kc == 32) {
         if (epl == 0) return launch_gemm<RS, 32, true, 0>(h, NB, lds, st, nw);
         if (epl == 1) return launch_gemm<RS, 32, true, 1>(h, NB, lds, st, nw);
@@ -532,8 +541,10 @@ int plan_gemm(const trunet_gemm_args* h, GemmPlan* pl) {
     }
     int rs0 = h->M > 64 ? 4 : (h->M > 32 ? 2 : 1);
     const size_t budget = 160 * 1024;
+    static const bool kc8_ok = !(getenv("TRUNET_GEMM_KC8") && getenv("TRUNET_GEMM_KC8")[0] == '0');
+    const bool thin_k = kc8_ok && two && rs0 == 2 && h->nseg == 1 && nchan_total <= 8;
     for (int rs = rs0; rs >= 1; rs >>= 1) {
-        for (int kc = 32; kc >= (two ? 16 : 32); kc >>= 1) {
+        for (int kc = thin_k ? 8 : 32; kc >= (thin_k ? 8 : (two ? 16 : 32)); kc >>= 1) {
             int kpad = 0;
             for (int s = 0; s < h->nseg; ++s) kpad += (h->seg[s].nchan + kc - 1) / kc * kc;
             const size_t slot = (size_t)kc * NT * sizeof(float) * (two ? 2 : 1);

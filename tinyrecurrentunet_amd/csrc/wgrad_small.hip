@@ -8,6 +8,7 @@
 // (CB of its channels): every thread keeps its accumulators in registers, walks (position, 256-frame chunk) items with 16-byte loads (frames are contiguous), and
 // the block reduces its accumulators once at the end into its part of the partial image (trunet_reduce_partials
 // sums the images exactly as for conv_wgrad_kernel).
+#include <cstdlib>
 #include "common.hpp"
 
 namespace {
@@ -163,6 +164,157 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const trunet_wgrad_arg
     }
 }
 
+// ---- encoder.0's Conv1d(C_in <= 4 -> 64, k = NS taps, stride 2) (network.py:13), round 3:
+//   dW[m][c][k] = sum_{p, n < N} dz[m][p][n] x[c][p mul + off_k][n],   db[m] = sum dz[m][p][n]
+// The launch is a pure stream of dz (64 x 128 x N floats = 1.05 GB at configs[1]); wgrad_small_kernel<4, 4, 5> gave every
+// 4-row group its own blocks and one (position, 256 frames) item per wave: 24 loads per item consumed as soon as they were
+// issued, 16 copies of x through the L2, an integer division per item -- 0.67 ms = 1.6 TB/s.
+// Here a block is 4 waves, ONE per SIMD (up to 512 registers each): wave w owns dz rows [32 rh + 8 w, + 8) -- rh = row half
+// of the block -- and all C_in x NS columns (160 accumulators); a block walks a contiguous range of (frame chunk, position)
+// items, positions fastest, all four waves on the same item (the item's x rows come from the L1 three times out of four),
+// and the loads of item t + 1 (8 dz rows, C_in x NS x rows: 28 x 16 bytes per lane) are in flight in a second register set
+// while item t's 640 FMAs per lane run.  Every dz row is read exactly once.
+template <int NS>
+__global__ __launch_bounds__(256, 1) void wgrad_first_kernel(const trunet_wgrad_args a) {
+    __shared__ float red[4][8 * 4 * NS + 8];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rh = blockIdx.x & 1, img_i = blockIdx.x >> 1, nimg = gridDim.x >> 1;
+    const int m0 = 32 * rh + 8 * wave;
+    const trunet_seg& s0 = a.seg[0];
+    const int C = s0.nchan;                               // <= 4 (host-checked), same for every tap
+    float acc[8][4][NS], bsum[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        bsum[i] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int k = 0; k < NS; ++k) acc[i][c][k] = 0.f;
+    }
+    int offk[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) offk[k] = a.seg[k].pos_off;
+    const int mul = s0.pos_mul, SL = s0.L;
+    const int nch = a.NP / 256;
+    const int items = a.P * nch;
+    const int i0 = (int)(((long long)img_i * items) / nimg);
+    const int i1 = (int)(((long long)(img_i + 1) * items) / nimg);
+    const size_t dstr = (size_t)a.a_L * a.NP, sstr = (size_t)SL * a.NP;
+    const bool rows_ok = m0 < a.M;                        // M is a multiple of 8 (host-checked)
+    // software pipeline: the 8 dz rows of item t + 1 are requested (second register set) before item t's FMAs start, and
+    // the x rows of channel c for item t + 1 replace those of item t as soon as channel c's FMAs are done
+    f32x4 xv[4][NS];
+    auto load_dz = [&](f32x4 (&dz)[8], int chunk, int pi) __attribute__((always_inline)) {
+        const float* pdz = a.a0 + ((size_t)(m0 + a.a_m_off) * a.a_L + a.p_begin + pi + a.a_pos_off) * a.NP + chunk * 256 + 4 * lane;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dz[i] = *(const f32x4*)(pdz + (size_t)i * dstr);
+    };
+    // (every load below is UNCONDITIONAL: a load inside a uniform branch makes hipcc's s_waitcnt pass give up counting at
+    // the merge point and drain the whole queue -- vmcnt(0) in front of every channel -- which serialises the pipeline;
+    // out-of-range taps read a clamped row and are zeroed afterwards, the requests past the last item repeat it)
+    auto load_x = [&](int c, int chunk, int pi) __attribute__((always_inline)) {
+        const int p = a.p_begin + pi;
+        const float* px = s0.src0 + (size_t)min(c, C - 1) * sstr + chunk * 256 + 4 * lane;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int q = p * mul + offk[k];
+            xv[c][k] = *(const f32x4*)(px + (size_t)min(max(q, 0), SL - 1) * a.NP);
+        }
+    };
+    auto fix_x = [&](int c, int pi) __attribute__((always_inline)) {       // conv padding / absent channels read as zero
+        const int p = a.p_begin + pi;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int q = p * mul + offk[k];
+            if (!(c < C && q >= 0 && q < SL)) xv[c][k] = f32x4{0.f, 0.f, 0.f, 0.f};    // uniform, rare
+        }
+    };
+    auto consume = [&](f32x4 (&dz)[8], int chunk, int pi, int nchunk, int npi) __attribute__((always_inline)) {
+        if (chunk * 256 + 256 > a.N) {                    // uniform: only the last chunk holds frames >= N
+            const int n = chunk * 256 + 4 * lane;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e >= a.N) dz[i][e] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bsum[i] += (dz[i][0] + dz[i][1]) + (dz[i][2] + dz[i][3]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            fix_x(c, pi);
+#pragma unroll
+            for (int k = 0; k < NS; ++k)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][c][k] = fmaf(dz[i][e], xv[c][k][e], acc[i][c][k]);
+            __builtin_amdgcn_sched_barrier(0);
+            load_x(c, nchunk, npi);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if (rows_ok && i0 < i1) {
+        // dz rows of items t + 1 and t + 2 in flight while item t computes (three register sets): with one item ahead a CU
+        // had 32 KB of the HBM stream in flight and the kernel sat at 2.9 TB/s
+        f32x4 dzA[8], dzB[8], dzC[8];
+        int chunk = i0 / a.P, pi = i0 - chunk * a.P;
+        auto next = [&](int& ch, int& pp, bool more) __attribute__((always_inline)) {
+            if (more && ++pp == a.P) { pp = 0; ++ch; }     // past the last item: stay on it (a redundant, harmless request)
+        };
+        int c1 = chunk, p1 = pi;
+        next(c1, p1, i0 + 1 < i1);
+        load_dz(dzA, chunk, pi);
+        load_dz(dzB, c1, p1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) load_x(c, chunk, pi);
+        for (int it = i0; it < i1; it += 3) {
+            // items it (chunk, pi) in dzA, it + 1 (c1, p1) in dzB; it + 2 .. it + 4 are requested below
+            int c2 = c1, p2 = p1;
+            next(c2, p2, it + 2 < i1);
+            int c3 = c2, p3 = p2;
+            next(c3, p3, it + 3 < i1);
+            int c4 = c3, p4 = p3;
+            next(c4, p4, it + 4 < i1);
+            load_dz(dzC, c2, p2);
+            consume(dzA, chunk, pi, c1, p1);
+            load_dz(dzA, c3, p3);
+            if (it + 1 < i1) consume(dzB, c1, p1, c2, p2);
+            load_dz(dzB, c4, p4);
+            if (it + 2 < i1) consume(dzC, c2, p2, c3, p3);
+            chunk = c3; pi = p3; c1 = c4; p1 = p4;
+        }
+    }
+    // ---- this block's rows of partial image img_i: wave w writes its 8 rows
+    float* img = a.w_partials + (size_t)img_i * a.w_numel;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const float v = wave_sum(acc[i][c][k]);
+                if (lane == 0) red[wave][(i * 4 + c) * NS + k] = v;
+            }
+        const float b = wave_sum(bsum[i]);
+        if (lane == 0) red[wave][8 * 4 * NS + i] = b;
+    }
+    __syncthreads();
+    if (rows_ok) {
+        for (int idx = lane; idx < 8 * 4 * NS + 8; idx += 64) {
+            const float v = red[wave][idx];
+            if (idx < 8 * 4 * NS) {
+                const int i = idx / (4 * NS), r = idx - i * (4 * NS), c = r / NS, k = r - c * NS;
+                if (c < C)
+                    img[(size_t)(m0 + i + a.w_m_off) * a.ldw_m + (size_t)c * a.ldw_c + a.seg[k].woff] = v;
+            } else if (a.b_partials) {
+                a.b_partials[(size_t)img_i * a.b_stride + a.b_off + m0 + (idx - 8 * 4 * NS)] = v;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // called by trunet_conv_wgrad (gemm_conv.hip) for the thin shapes; returns TRUNET_ENOTSUP when the shape is not thin
@@ -173,6 +325,17 @@ int trunet_launch_wgrad_small(const trunet_wgrad_args* h, hipStream_t st) {
         maxc = h->seg[s].nchan > maxc ? h->seg[s].nchan : maxc;
         same = same && h->seg[s].src0 == h->seg[0].src0 && h->seg[s].nchan == h->seg[0].nchan &&
                h->seg[s].mode == h->seg[0].mode && h->seg[s].c0 == h->seg[0].c0 && h->seg[s].c1 == h->seg[0].c1;
+    }
+    static const bool first_ok = !(getenv("TRUNET_WGRAD_FIRST") && getenv("TRUNET_WGRAD_FIRST")[0] == '0');
+    if (first_ok && maxc <= 4 && same && h->nseg == 5 && h->M <= 64 && (h->M % 8) == 0 && h->a_mode == TRUNET_PRO_NONE &&
+        h->seg[0].mode == TRUNET_PRO_NONE && h->seg[0].pos_div == 1 && (h->NP % 256) == 0) {
+        bool taps = true;                           // the five segments are the taps of ONE strided conv
+        for (int s = 1; s < h->nseg; ++s)
+            taps = taps && h->seg[s].pos_mul == h->seg[0].pos_mul && h->seg[s].pos_div == 1 && h->seg[s].L == h->seg[0].L;
+        if (taps) {
+            hipLaunchKernelGGL((wgrad_first_kernel<5>), dim3(2 * WS_GRID), dim3(256), 0, st, *h);
+            return trunet_launch_status();
+        }
     }
     if (maxc <= 4 && same) {                    // encoder.0 Conv1d(4 -> 64, k5): 4 rows of dz x all taps per role
         const int ngm = (h->M + 3) / 4;
