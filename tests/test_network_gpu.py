@@ -269,6 +269,14 @@ def test_first_conv_backward_vs_oracle_f64_on_256_frame_chunks(N):
     _block_vs_f64("std", N, ptol=1e-3 if N < 2000 else 2e-3)
 
 
+@pytest.mark.parametrize("N", [1000, 8448])
+def test_last_block_backward_vs_oracle_f64_on_256_frame_chunks(N):
+    """LastTrCNN (network.py:102-120) at padded frame counts that are multiples of 256: the ConvTranspose1d(8 -> 8) weight
+    gradient runs on wgrad_last_kernel and the data gradients of the 128 -> 8 pointwise layer on the 8-row-chunk
+    conv_gemm instances (round 3)"""
+    _block_vs_f64("last_tr", N, ptol=1e-3 if N < 2000 else 2e-3, zero_floor=2e-2 * max(1.0, N / 777.0) ** 0.5)
+
+
 def _block_vs_f64(name, N, ptol=1e-3, zero_floor=2e-2):
     from oracle import network_ref as nr, weights as W
     from tinyrecurrentunet_amd import network as hn

@@ -315,6 +315,143 @@ __global__ __launch_bounds__(256, 1) void wgrad_first_kernel(const trunet_wgrad_
     }
 }
 
+// ---- decoder.5's ConvTranspose1d(8 -> 8, k = NS taps, stride 2) (network.py:109), round 3:
+//   dW[ci][co][k] = sum_{p, n < N} dz[co][p][n] a[ci][(p + pad - k) / 2][n]   (taps with p + pad - k even),  db[co] = sum dz
+// a = max(c0 z + c1, 0) of the 8-channel pointwise output.  The launch reads dz (8 x 257 rows) and z (8 x 128 rows) once:
+// 12 KB per frame, 0.39 GB at configs[1]; wgrad_small_kernel<8, 8, 1> gave every tap its own blocks (dz through the L2 five
+// times, 16 loads per item consumed at once): 0.355 ms = 1.1 TB/s.  Same recipe as wgrad_first_kernel: a block of 4 waves,
+// one per SIMD, walks a contiguous range of (frame chunk, position) items, all waves on the same item; wave w owns source
+// channels {2 w, 2 w + 1} x all 8 dz rows x all taps (80 accumulators); the next item's dz and source rows are requested
+// into a second register set before the current item's FMAs; loads are unconditional (clamped rows), invalid taps skip
+// their FMAs (uniform).
+template <int NS>
+__global__ __launch_bounds__(256, 1) void wgrad_last_kernel(const trunet_wgrad_args a) {
+    __shared__ float red[4][8 * 2 * NS + 8];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c0 = 2 * wave;
+    const trunet_seg& s0 = a.seg[0];
+    const bool on = s0.mode == TRUNET_PRO_BNRELU;
+    float k0[2], k1[2], klo[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ci = min(c0 + j, s0.nchan - 1);
+        k0[j] = on ? s0.c0[ci] : 1.f;
+        k1[j] = on ? s0.c1[ci] : 0.f;
+        klo[j] = on ? 0.f : -3.0e38f;
+    }
+    float acc[8][2][NS], bsum[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        bsum[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < NS; ++k) acc[i][j][k] = 0.f;
+    }
+    int offk[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) offk[k] = a.seg[k].pos_off;
+    const int SL = s0.L;
+    const int nch = a.NP / 256;
+    const int items = a.P * nch;
+    const int i0 = (int)(((long long)blockIdx.x * items) / gridDim.x);
+    const int i1 = (int)(((long long)(blockIdx.x + 1) * items) / gridDim.x);
+    const size_t dstr = (size_t)a.a_L * a.NP, sstr = (size_t)SL * a.NP;
+    struct Item { f32x4 dz[8]; f32x4 sv[2][NS]; };
+    auto request = [&](Item& r, int chunk, int pi) __attribute__((always_inline)) {
+        const int p = a.p_begin + pi;
+        const int n = chunk * 256 + 4 * lane;
+        const float* pdz = a.a0 + ((size_t)a.a_m_off * a.a_L + p + a.a_pos_off) * a.NP + n;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r.dz[i] = *(const f32x4*)(pdz + (size_t)min(i, a.M - 1) * dstr);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int q = (p + offk[k]) >> 1;
+                r.sv[j][k] = *(const f32x4*)(s0.src0 + (size_t)min(c0 + j, s0.nchan - 1) * sstr +
+                                              (size_t)min(max(q, 0), SL - 1) * a.NP + n);
+            }
+    };
+    auto consume = [&](Item& r, int chunk, int pi) __attribute__((always_inline)) {
+        const int p = a.p_begin + pi;
+        if (chunk * 256 + 256 > a.N) {                    // uniform: only the last chunk holds frames >= N
+            const int n = chunk * 256 + 4 * lane;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e >= a.N) r.dz[i][e] = 0.f;
+        }
+        if (wave == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bsum[i] += (r.dz[i][0] + r.dz[i][1]) + (r.dz[i][2] + r.dz[i][3]);
+        }
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int qn = p + offk[k];
+            const int q = qn >> 1;
+            if (qn >= 0 && !(qn & 1) && q < SL) {          // uniform: the taps of this position's parity
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x4 v = r.sv[j][k];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], k0[j], k1[j]), klo[j]);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j][k] = fmaf(r.dz[i][e], v[e], acc[i][j][k]);
+                }
+            }
+        }
+    };
+    if (i0 < i1) {
+        Item A_, B_;
+        int chunk = i0 / a.P, pi = i0 - chunk * a.P;
+        auto next = [&](int& ch, int& pp, bool more) __attribute__((always_inline)) {
+            if (more && ++pp == a.P) { pp = 0; ++ch; }     // past the last item: stay on it (a redundant, harmless request)
+        };
+        request(A_, chunk, pi);
+        for (int it = i0; it < i1; it += 2) {
+            int c1 = chunk, p1 = pi;
+            next(c1, p1, it + 1 < i1);
+            int c2 = c1, p2 = p1;
+            next(c2, p2, it + 2 < i1);
+            request(B_, c1, p1);
+            consume(A_, chunk, pi);
+            request(A_, c2, p2);
+            if (it + 1 < i1) consume(B_, c1, p1);
+            chunk = c2; pi = p2;
+        }
+    }
+    float* img = a.w_partials + (size_t)blockIdx.x * a.w_numel;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const float v = wave_sum(acc[i][j][k]);
+                if (lane == 0) red[wave][(i * 2 + j) * NS + k] = v;
+            }
+        const float b = wave_sum(bsum[i]);
+        if (lane == 0) red[wave][8 * 2 * NS + i] = b;
+    }
+    __syncthreads();
+    for (int idx = lane; idx < 8 * 2 * NS + 8; idx += 64) {
+        const float v = red[wave][idx];
+        if (idx < 8 * 2 * NS) {
+            const int i = idx / (2 * NS), r = idx - i * (2 * NS), j = r / NS, k = r - j * NS;
+            if (i < a.M && c0 + j < s0.nchan)
+                img[(size_t)(i + a.w_m_off) * a.ldw_m + (size_t)(c0 + j) * a.ldw_c + a.seg[k].woff] = v;
+        } else if (wave == 0 && a.b_partials) {
+            const int i = idx - 8 * 2 * NS;
+            if (i < a.M) a.b_partials[(size_t)blockIdx.x * a.b_stride + a.b_off + i] = v;
+        }
+    }
+}
+
 }  // namespace
 
 // called by trunet_conv_wgrad (gemm_conv.hip) for the thin shapes; returns TRUNET_ENOTSUP when the shape is not thin
@@ -341,6 +478,17 @@ int trunet_launch_wgrad_small(const trunet_wgrad_args* h, hipStream_t st) {
         const int ngm = (h->M + 3) / 4;
         hipLaunchKernelGGL((wgrad_small_kernel<4, 4, TRUNET_MAX_SEG>), dim3(ngm, WS_GRID), dim3(256), 0, st, *h, ngm, 1);
         return trunet_launch_status();
+    }
+    static const bool last_ok = !(getenv("TRUNET_WGRAD_LAST") && getenv("TRUNET_WGRAD_LAST")[0] == '0');
+    if (last_ok && h->M <= 8 && maxc <= 8 && same && h->nseg == 5 && h->a_mode == TRUNET_PRO_NONE && (h->NP % 256) == 0) {
+        bool taps = true;                           // the five segments are the taps of ONE stride-2 transposed conv
+        for (int s = 0; s < h->nseg; ++s)
+            taps = taps && h->seg[s].pos_mul == 1 && h->seg[s].pos_div == 2 && h->seg[s].L == h->seg[0].L &&
+                   h->seg[s].mode != TRUNET_PRO_BNBWD;
+        if (taps) {
+            hipLaunchKernelGGL((wgrad_last_kernel<5>), dim3(WS_GRID), dim3(256), 0, st, *h);
+            return trunet_launch_status();
+        }
     }
     if (h->M <= 8 && maxc <= 8) {               // decoder.5 ConvTranspose1d(8 -> 8, k5): one tap per role
         hipLaunchKernelGGL((wgrad_small_kernel<8, 8, 1>), dim3(h->nseg, WS_GRID), dim3(256), 0, st, *h, 1, 1);
