@@ -213,8 +213,9 @@ def streaming(args, dev, emit=True):
                 "traffic": None, "avg_launch_ms": round(kms, 4),
                 # features in + output out per frame (+ the hidden state read and written: 2 x 8 KB)
                 "algorithmic_bytes_per_launch": streams * (12336 + (16384 if args.tgru else 0)),
-                "note": "per-frame independent eval forward, one workgroup per frame: bound by the fp32 MFMA rate "
-                        "(31.4 Mflop vs 12.3 KB per frame)"}
+                "note": ("one workgroup per frame through all layers in its own LDS: bound by the fp32 MFMA rate (%s)" % (
+                    "34.0 Mflop vs 28.7 KB per frame incl. the hidden state" if args.tgru else
+                    "31.4 Mflop vs 12.3 KB per frame"))}
     cpu = None
     if not args.no_cpu_baseline and not args.tgru:
         from oracle import network_ref as nr
@@ -287,7 +288,8 @@ def other_configs(args, dev, step_factory):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default 20; 200 with --streaming: a step is 0.45 ms there)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
     ap.add_argument("--seconds", type=float, default=4.0)
@@ -306,6 +308,8 @@ def main():
     ap.add_argument("--streaming", action="store_true",
                     help="BASELINE.json configs[3]: 1-frame causal forward of 1024 concurrent streams (rt.py protocol)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 200 if args.streaming else 20
     if args.dtype == "bf16" and (args.tgru or args.streaming):
         raise SystemExit("bench.py --dtype bf16: the TGRU block and the streaming forward are fp32 only")
 
