@@ -486,6 +486,31 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
     for (int i = 0; i < BW_MAXT; ++i) pc_t[i] = posc(t_seg[i]);
 #pragma unroll
     for (int i = 0; i < BW_MAXG; ++i) pc_d[i] = posc(d_seg[i]);
+    // Everything a step needs from the argument block is read ONCE here: inside the step loop a.seg[<runtime index>] /
+    // dg.out[<runtime index>] are scalar loads from the kernarg segment, each followed by s_waitcnt lgkmcnt(0) -- which also
+    // waits for every LDS access in flight -- about ten times per step (flags, output pointer and row length per quarter tile).
+    const u32x4* s_ptr[BW_MAXS];                  // row 0 of this wave's source octet j
+    bool s_plain[BW_MAXS];                        // whole octets of a source without prologue: copied as they are
+#pragma unroll
+    for (int j = 0; j < BW_MAXS; ++j) {
+        const trunet_bseg& sg = a.seg[max(soct_seg[j], 0)];
+        s_ptr[j] = (const u32x4*)sg.src0 + (size_t)soct_idx[j] * sg.L * a.NP;
+        s_plain[j] = SMODE == TRUNET_PRO_NONE && (sg.nchan & 7) == 0;
+    }
+    int d_flags[BW_MAXG], d_gstride[BW_MAXG];     // TRUNET_DG_* of the tile's segment; u32x2 elements between its octets
+    u32x2* d_out[BW_MAXG];                        // (first octet of the tile, position 0, frame 0, half 0) of its output
+#pragma unroll
+    for (int i = 0; i < BW_MAXG; ++i) {
+        d_flags[i] = 0; d_gstride[i] = 0; d_out[i] = nullptr;
+        if constexpr (DG) {
+            if (d_seg[i] >= 0) {
+                const trunet_bseg& sg = a.seg[d_seg[i]];
+                d_flags[i] = dg.flags[d_seg[i]];
+                d_gstride[i] = sg.L * a.NP * 2;
+                d_out[i] = (u32x2*)dg.out[d_seg[i]] + (size_t)(d_rtl[i] * 4) * sg.L * a.NP * 2;
+            }
+        }
+    }
     auto issue = [&](const Info& f, Stage& r) {
         const int p = f.p;
         const size_t n = (size_t)f.chunk * BW_F + lane;
@@ -501,10 +526,9 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
 #pragma unroll
         for (int j = 0; j < BW_MAXS; ++j) {
             if (soct_seg[j] >= 0) {
-                const trunet_bseg& sg = a.seg[soct_seg[j]];
                 bool valid; int q;
                 pos(pc_s[j], f.p, valid, q);
-                if (valid) r.s[j] = BW_LD((const u32x4*)sg.src0 + ((size_t)soct_idx[j] * sg.L + q) * a.NP + n);
+                if (valid) r.s[j] = BW_LD(s_ptr[j] + (size_t)q * a.NP + n);
             }
         }
     };
@@ -515,20 +539,18 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
             const int h = lane >> 5, c = lane & 31;
 #pragma unroll
             for (int i = 0; i < BW_MAXG; ++i) {
-                if (d_seg[i] < 0 || !(dg.flags[d_seg[i]] & 8)) continue;
+                if (d_seg[i] < 0 || !(d_flags[i] & 8)) continue;
 #if defined(BW_ABL) && (BW_ABL & 64)     // diagnostic: the accumulate operands are not loaded
                 if (a.N >= 0) continue;
 #endif
                 bool valid; int q;
                 pos(pc_d[i], f.p, valid, q);
                 if (!valid) continue;
-                const trunet_bseg& sg = a.seg[d_seg[i]];
                 const int cb = ((7 - wave) + 8 * i) & 1;
                 const int nn = f.chunk * BW_F + 32 * cb + c;
-                const u32x2* outp = (const u32x2*)dg.out[d_seg[i]];
+                const u32x2* op = d_out[i] + ((size_t)q * a.NP + nn) * 2 + h;
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4)
-                    o[i][g4] = outp[(((size_t)(d_rtl[i] * 4 + g4) * sg.L + q) * a.NP + nn) * 2 + h];
+                for (int g4 = 0; g4 < 4; ++g4) o[i][g4] = op[(size_t)g4 * d_gstride[i]];
             }
         }
     };
@@ -566,7 +588,6 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
 #pragma unroll
         for (int j = 0; j < BW_MAXS; ++j) {
             if (soct_seg[j] >= 0) {
-                const trunet_bseg& sg = a.seg[soct_seg[j]];
                 bool valid; int q;
                 pos(pc_s[j], f.p, valid, q);
                 if (valid) {
@@ -574,7 +595,7 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
 #if defined(BW_ABL) && (BW_ABL & 2)      // diagnostic (wrong results): no source prologue
                     if (true) {
 #else
-                    if (SMODE == TRUNET_PRO_NONE && (sg.nchan & 7) == 0) {
+                    if (s_plain[j]) {
 #endif
                         *(u32x4*)(buf + (moct + soct_g[j]) * BW_OS + lane * 16) = r.s[j];       // raw operand
                     } else {
@@ -621,10 +642,9 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
                     const bf16x8 bfr = __builtin_bit_cast(bf16x8, *(const u32x4*)(bcol + 2 * ks * BW_OS));
                     d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, d, 0, 0, 0);
                 }
-                const trunet_bseg& sg = a.seg[d_seg[i]];
-                const int flags = dg.flags[d_seg[i]];
-                u32x2* outp = (u32x2*)dg.out[d_seg[i]];
+                const int flags = d_flags[i];
                 const int nn = f.chunk * BW_F + 32 * cb + c;
+                u32x2* outp = d_out[i] + ((size_t)q * a.NP + nn) * 2 + h;
                 const bool fin = nn < a.N;
                 float st1[16], st2[16];
 #if defined(BW_ABL) && (BW_ABL & 16)     // diagnostic: no data-gradient epilogue (one guarded store keeps the MFMAs alive)
@@ -634,7 +654,7 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bwgrad_kernel(const trunet_bwgr
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int og = d_og[i] + g4;
-                    const size_t eidx = (((size_t)(d_rtl[i] * 4 + g4) * sg.L + q) * a.NP + nn) * 2 + h;
+                    const size_t eidx = (size_t)g4 * d_gstride[i];
                     float val[4], zv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) val[e] = d[4 * g4 + e];
