@@ -50,6 +50,15 @@ def spawn_ranks(n):
         env.setdefault("OMP_NUM_THREADS", "1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=(None if r == 0 else sys.stderr)))
+    import signal
+
+    def _stop(signum, frame):                   # the launcher is told to stop: take the ranks down with it (by PID)
+        for q in procs:
+            if q.poll() is None:
+                q.terminate()
+        raise SystemExit(128 + signum)
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sig, _stop)
     rc = 0
     alive = list(procs)
     while alive:

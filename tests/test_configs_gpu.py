@@ -110,7 +110,10 @@ def test_cfg2_full_size_train_step_vs_oracle():
     out_dir = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(__file__)), "gpurun_out")
     if __import__("os").path.isdir(out_dir):
         open(__import__("os").path.join(out_dir, "parity_fullsize.txt"), "a").write(msg + "\n")
-    assert float(np.median(errs)) < 2.5e-2, float(np.median(errs))
+    # measured (round 3): median 1.5e-3, max 9.4e-3 -- sums over 32,064 frames are better conditioned than the N = 300 ones the
+    # whole-network bounds were set on; a 3 % error in one layer's weight gradient does not pass here
+    assert float(np.median(errs)) < 6e-3, float(np.median(errs))
+    assert max(errs) < 3e-2, max(errs)
 
 
 @pytest.mark.parametrize("graph", [False, True])
