@@ -64,7 +64,10 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(const trunet_bgemm_args a
     float* Cf = (float*)(Al + (size_t)nrt_all * a.nks_total * 64);      // [nks_total][2 octets][3][8] coefficients
     float* Ep = Cf + a.nks_total * 2 * 3 * 8;                           // [4][128] epilogue: bias, e0, e1, e2 (LDS, not 128
                                                                         // hoisted registers)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (wave through readfirstlane: without it the tile index, its division by P, the segment positions and every row base
+    // address were per-LANE integer arithmetic -- 22 quarter-rate v_mul_lo_u32 per tile -- and `continue` on an invalid
+    // segment an exec-mask branch)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, c = lane & 31;
     const int epi = EPI >= 0 ? EPI : a.epi;
     auto has = [&](int f) { return EPI >= 0 ? (EPI & f) != 0 : (epi & f) != 0; };
