@@ -327,8 +327,45 @@ __global__ __launch_bounds__(256) void mask_istft_bwd_kernel(const float* __rest
     }
 }
 
+// One windowed frame pair z = w x + j w y into LDS, and the n/2 twiddles next to it.  NI = n / 256 is a COMPILE-TIME
+// count (2 / 4 / 8 for the three resolutions of config/tiny.json), so that a thread's NI (reflected) samples of both
+// signals are requested before the first one is used: as a `for (i = tid; i < n; i += 256)` loop of unknown trip count
+// hipcc issued load, wait, LDS store per iteration -- eight L2 round trips in a row at n = 2048, most of the ~12 us a
+// block of these kernels took (round 3).  NI = 0: any other n (runtime loops).
+template <int NI, bool YZERO>
+__device__ __forceinline__ void stft_stage_frame(cpx* sa, cpx* stw, const float* __restrict__ xb,
+                                                 const float* __restrict__ yb, const float* __restrict__ win,
+                                                 const cpx* __restrict__ tw, int f, int hop, int n, int L) {
+    if constexpr (NI > 0) {
+        float vx[NI], vy[NI], w[NI];
+        cpx t[NI / 2 > 0 ? NI / 2 : 1];
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int i = threadIdx.x + 256 * it;
+            const int j = reflect_idx(f * hop + i - n / 2, L);
+            vx[it] = xb[j];
+            vy[it] = YZERO ? 0.f : yb[j];
+            w[it] = win[i];
+        }
+#pragma unroll
+        for (int it = 0; it < NI / 2; ++it) t[it] = tw[threadIdx.x + 256 * it];
+#pragma unroll
+        for (int it = 0; it < NI; ++it) sa[threadIdx.x + 256 * it] = make_float2(w[it] * vx[it], w[it] * vy[it]);
+#pragma unroll
+        for (int it = 0; it < NI / 2; ++it) stw[threadIdx.x + 256 * it] = t[it];
+    } else {
+        for (int i = threadIdx.x; i < n / 2; i += 256) stw[i] = tw[i];
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int j = reflect_idx(f * hop + i - n / 2, L);
+            const float w = win[i];
+            sa[i] = make_float2(w * xb[j], YZERO ? 0.f : w * yb[j]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- multi-resolution STFT loss
 // one block per (frame f, signal b): z = w*x + j w*y -> FFT -> |X|, |Y| -> three sums
+template <int NI>
 __global__ __launch_bounds__(256) void stft_loss_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                             const float* __restrict__ win, const cpx* __restrict__ tw,
                                                             float* __restrict__ partials, int L, int n, int logn, int hop,
@@ -338,16 +375,11 @@ __global__ __launch_bounds__(256) void stft_loss_fwd_kernel(const float* __restr
     cpx* sb = sa + n;
     cpx* stw = sb + n;                       // the n/2 twiddles, staged once per block (three table reads per butterfly
                                              // from global memory were most of a stage's latency)
-    for (int i = threadIdx.x; i < n / 2; i += 256) stw[i] = tw[i];
     __shared__ double red[12];
     const int f = blockIdx.x, b = blockIdx.y;
     const float* xb = x + (size_t)b * L;
     const float* yb = y + (size_t)b * L;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int j = reflect_idx(f * hop + i - n / 2, L);
-        const float w = win[i];
-        sa[i] = make_float2(w * xb[j], w * yb[j]);
-    }
+    stft_stage_frame<NI, false>(sa, stw, xb, yb, win, tw, f, hop, n, L);
     const cpx* Z = fft_lds(sa, sb, n, logn, stw, false);
     float s1 = 0.f, s2 = 0.f, s3 = 0.f;
     for (int k = threadIdx.x; k <= n / 2; k += 256) {
@@ -373,6 +405,7 @@ __global__ __launch_bounds__(256) void stft_loss_fwd_kernel(const float* __restr
 }
 
 // stft() of stft_loss.py:9-30 for two signals at once: magnitudes sqrt(clamp(re^2 + im^2, 1e-7)) as (B, frames, bins)
+template <int NI>
 __global__ __launch_bounds__(256) void stft_mag_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                        const float* __restrict__ win, const cpx* __restrict__ tw,
                                                        float* __restrict__ xmag, float* __restrict__ ymag, int L, int n,
@@ -381,15 +414,10 @@ __global__ __launch_bounds__(256) void stft_mag_kernel(const float* __restrict__
     cpx* sa = (cpx*)smraw;
     cpx* sb = sa + n;
     cpx* stw = sb + n;
-    for (int i = threadIdx.x; i < n / 2; i += 256) stw[i] = tw[i];
     const int f = blockIdx.x, b = blockIdx.y;
     const float* xb = x + (size_t)b * L;
     const float* yb = y + (size_t)b * L;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int j = reflect_idx(f * hop + i - n / 2, L);
-        const float w = win[i];
-        sa[i] = make_float2(w * xb[j], w * yb[j]);
-    }
+    stft_stage_frame<NI, false>(sa, stw, xb, yb, win, tw, f, hop, n, L);
     const cpx* Z = fft_lds(sa, sb, n, logn, stw, false);
     const size_t base = ((size_t)b * nframes + f) * (n / 2 + 1);
     for (int k = threadIdx.x; k <= n / 2; k += 256) {
@@ -433,7 +461,7 @@ __global__ __launch_bounds__(1024) void reduce_cols_kernel(const float* __restri
 // Either way the frame FFT is recomputed, the gradient half spectrum g_xm * X / xm (zero where clamp(min=1e-7) is
 // active) goes through the inverse FFT, and the windowed real part over the window's support is written to `fr`
 // (B, frames, wl); ola_gather_kernel sums the frames per sample -- no float atomics.
-template <bool MAG>
+template <bool MAG, int NI>
 __global__ __launch_bounds__(256) void stft_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                        const float* __restrict__ win, const cpx* __restrict__ tw,
                                                        const float* __restrict__ coef, const float* __restrict__ gmag,
@@ -443,15 +471,10 @@ __global__ __launch_bounds__(256) void stft_bwd_kernel(const float* __restrict__
     cpx* sa = (cpx*)smraw;
     cpx* sb = sa + n;
     cpx* stw = sb + n;
-    for (int i = threadIdx.x; i < n / 2; i += 256) stw[i] = tw[i];
     const int f = blockIdx.x, b = blockIdx.y;
     const float* xb = x + (size_t)b * L;
     const float* yb = MAG ? xb : y + (size_t)b * L;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int j = reflect_idx(f * hop + i - n / 2, L);
-        const float w = win[i];
-        sa[i] = make_float2(w * xb[j], MAG ? 0.f : w * yb[j]);
-    }
+    stft_stage_frame<NI, MAG>(sa, stw, xb, yb, win, tw, f, hop, n, L);
     cpx* Z = fft_lds(sa, sb, n, logn, stw, false);
     cpx* other = (Z == sa) ? sb : sa;
     const float c_sc = MAG ? 0.f : coef[0], c_mag = MAG ? 0.f : coef[1];
@@ -603,8 +626,10 @@ extern "C" int trunet_stft_loss_fwd(const float* x, const float* y, const float*
     const int logn = ilog2(n);
     if (!x || !y || !win || !tw || !partials || B <= 0 || logn < 3 || n > 4096 || hop <= 0 || L <= n / 2) return TRUNET_EINVAL;
     const int nframes = 1 + L / hop;
-    hipLaunchKernelGGL(stft_loss_fwd_kernel, dim3(nframes, B), dim3(256), (2 * n + n / 2) * sizeof(cpx), ST, x, y, win, (const cpx*)tw,
-                       partials, L, n, logn, hop, nframes);
+#define FWD_(NI_) hipLaunchKernelGGL(stft_loss_fwd_kernel<NI_>, dim3(nframes, B), dim3(256), (2 * n + n / 2) * sizeof(cpx), ST, x, y, \
+                                    win, (const cpx*)tw, partials, L, n, logn, hop, nframes)
+    if (n == 512) FWD_(2); else if (n == 1024) FWD_(4); else if (n == 2048) FWD_(8); else FWD_(0);
+#undef FWD_
     return trunet_launch_status();
 }
 
@@ -613,8 +638,10 @@ extern "C" int trunet_stft_mag(const float* x, const float* y, const float* win,
     const int logn = ilog2(n);
     if (!x || !win || !tw || !xmag || B <= 0 || logn < 3 || n > 4096 || hop <= 0 || L <= n / 2) return TRUNET_EINVAL;
     const int nframes = 1 + L / hop;
-    hipLaunchKernelGGL(stft_mag_kernel, dim3(nframes, B), dim3(256), (2 * n + n / 2) * sizeof(cpx), ST, x, y ? y : x, win,
-                       (const cpx*)tw, xmag, y ? ymag : nullptr, L, n, logn, hop, nframes);
+#define MAG_(NI_) hipLaunchKernelGGL(stft_mag_kernel<NI_>, dim3(nframes, B), dim3(256), (2 * n + n / 2) * sizeof(cpx), ST, x, y ? y : x, \
+                                    win, (const cpx*)tw, xmag, y ? ymag : nullptr, L, n, logn, hop, nframes)
+    if (n == 512) MAG_(2); else if (n == 1024) MAG_(4); else if (n == 2048) MAG_(8); else MAG_(0);
+#undef MAG_
     return trunet_launch_status();
 }
 
@@ -627,8 +654,10 @@ extern "C" int trunet_stft_loss_bwd_gather(const float* x, const float* y, const
         return TRUNET_EINVAL;
     const int nframes = 1 + L / hop;
     const int left = (n - win_length) / 2;
-    hipLaunchKernelGGL(stft_bwd_kernel<false>, dim3(nframes, B), dim3(256), (2 * n + n / 2) * sizeof(cpx), ST, x, y, win,
-                       (const cpx*)tw, coef, (const float*)nullptr, L, n, logn, hop, frames, win_length, left);
+#define BWD_(NI_) hipLaunchKernelGGL((stft_bwd_kernel<false, NI_>), dim3(nframes, B), dim3(256), (2 * n + n / 2) * sizeof(cpx), ST, x, y, \
+                                    win, (const cpx*)tw, coef, (const float*)nullptr, L, n, logn, hop, frames, win_length, left)
+    if (n == 512) BWD_(2); else if (n == 1024) BWD_(4); else if (n == 2048) BWD_(8); else BWD_(0);
+#undef BWD_
     hipLaunchKernelGGL(ola_gather_kernel, dim3((L + 255) / 256, B), dim3(256), 0, ST, frames, gx, L, n, hop, nframes,
                        win_length, left);
     return trunet_launch_status();
@@ -642,8 +671,10 @@ extern "C" int trunet_stft_mag_bwd(const float* x, const float* win, const float
         return TRUNET_EINVAL;
     const int nframes = 1 + L / hop;
     const int left = (n - win_length) / 2;
-    hipLaunchKernelGGL(stft_bwd_kernel<true>, dim3(nframes, B), dim3(256), (2 * n + n / 2) * sizeof(cpx), ST, x, x, win,
-                       (const cpx*)tw, (const float*)nullptr, gmag, L, n, logn, hop, frames, win_length, left);
+#define BWD_(NI_) hipLaunchKernelGGL((stft_bwd_kernel<true, NI_>), dim3(nframes, B), dim3(256), (2 * n + n / 2) * sizeof(cpx), ST, x, x, \
+                                    win, (const cpx*)tw, (const float*)nullptr, gmag, L, n, logn, hop, frames, win_length, left)
+    if (n == 512) BWD_(2); else if (n == 1024) BWD_(4); else if (n == 2048) BWD_(8); else BWD_(0);
+#undef BWD_
     hipLaunchKernelGGL(ola_gather_kernel, dim3((L + 255) / 256, B), dim3(256), 0, ST, frames, gx, L, n, hop, nframes,
                        win_length, left);
     return trunet_launch_status();
