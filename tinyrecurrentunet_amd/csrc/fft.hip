@@ -72,6 +72,74 @@ __device__ cpx* fft_lds(cpx* a, cpx* b, int n, int logn, const cpx* __restrict__
     return x;
 }
 
+// The same FFT with the size as a COMPILE-TIME constant (n = 2^LOGN, 256 threads): every stage's butterfly count per thread,
+// twiddle stride and index masks fold to constants and the stage loop unrolls.  The STFT-loss kernels run ~400 wave
+// instructions per block and are instruction-issue-bound (82k blocks x 4 waves at n = 512: the generic form above, with its
+// runtime `quarter / ns` divisions and masked index arithmetic, is most of that); round 3.
+template <int LOGN, bool INV>
+__device__ __forceinline__ cpx* fft_lds_t(cpx* a, cpx* b, const cpx* __restrict__ tw) {
+    constexpr int n = 1 << LOGN, half = n >> 1, quarter = n >> 2;
+    cpx* x = a;
+    cpx* y = b;
+    if constexpr (LOGN & 1) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < (half + 255) / 256; ++it) {
+            const int j = threadIdx.x + 256 * it;
+            if (half >= 256 || j < half) {
+                const cpx u = x[j], v = x[j + half];
+                y[2 * j] = make_float2(u.x + v.x, u.y + v.y);
+                y[2 * j + 1] = make_float2(u.x - v.x, u.y - v.y);
+            }
+        }
+        cpx* t = x; x = y; y = t;
+    }
+#pragma unroll
+    for (int s = (LOGN & 1); s < LOGN; s += 2) {
+        const int ns = 1 << s;                       // constant after unrolling
+        const int tstep = quarter >> s;
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < (quarter + 255) / 256; ++it) {
+            const int j = threadIdx.x + 256 * it;
+            if (quarter >= 256 || j < quarter) {
+                const int k = j & (ns - 1);
+                const int t1 = k * tstep;
+                cpx w1 = tw[t1], w2 = tw[2 * t1];
+                const int t3 = 3 * t1;
+                cpx w3 = tw[t3 >= half ? t3 - half : t3];
+                if (t3 >= half) { w3.x = -w3.x; w3.y = -w3.y; }
+                if (INV) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
+                const cpx u0 = x[j];
+                const cpx u1 = cmul(w1, x[j + quarter]);
+                const cpx u2 = cmul(w2, x[j + 2 * quarter]);
+                const cpx u3 = cmul(w3, x[j + 3 * quarter]);
+                const cpx v0 = make_float2(u0.x + u2.x, u0.y + u2.y);
+                const cpx v1 = make_float2(u0.x - u2.x, u0.y - u2.y);
+                const cpx v2 = make_float2(u1.x + u3.x, u1.y + u3.y);
+                const cpx d = make_float2(u1.x - u3.x, u1.y - u3.y);
+                const cpx v3 = INV ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x);
+                const int j0 = ((j - k) << 2) + k;
+                y[j0] = make_float2(v0.x + v2.x, v0.y + v2.y);
+                y[j0 + ns] = make_float2(v1.x + v3.x, v1.y + v3.y);
+                y[j0 + 2 * ns] = make_float2(v0.x - v2.x, v0.y - v2.y);
+                y[j0 + 3 * ns] = make_float2(v1.x - v3.x, v1.y - v3.y);
+            }
+        }
+        cpx* t = x; x = y; y = t;
+    }
+    __syncthreads();
+    return x;
+}
+// NI = n / 256 of the STFT-loss kernels -> log2 n (NI = 2, 4, 8); NI = 0: the runtime-sized form
+template <int NI, bool INV>
+__device__ __forceinline__ cpx* fft_lds_ni(cpx* a, cpx* b, int n, int logn, const cpx* __restrict__ tw) {
+    if constexpr (NI == 2) return fft_lds_t<9, INV>(a, b, tw);
+    else if constexpr (NI == 4) return fft_lds_t<10, INV>(a, b, tw);
+    else if constexpr (NI == 8) return fft_lds_t<11, INV>(a, b, tw);
+    else return fft_lds(a, b, n, logn, tw, INV);
+}
+
 __device__ __forceinline__ int reflect_idx(int j, int L) {
     if (j < 0) j = -j;
     if (j >= L) j = 2 * (L - 1) - j;
@@ -104,7 +172,7 @@ __global__ __launch_bounds__(256) void stft_features_kernel(const float* __restr
         const float vb = (t0 + 1 < T) ? x[reflect_idx((t0 + 1) * HOPF + i - NF / 2, L)] : 0.f;
         sa[i] = make_float2(va, vb);
     }
-    const cpx* Z = fft_lds(sa, sb, NF, 9, tw, false);
+    const cpx* Z = fft_lds_t<9, false>(sa, sb, tw);
     for (int k = threadIdx.x; k < BINS; k += 256) {
         cpx X[2];
         split_pair(Z, k, NF, X[0], X[1]);
@@ -222,7 +290,7 @@ __global__ __launch_bounds__(256) void mask_istft_frames_kernel(const float* __r
         sa[k] = make_float2(X[0].x - X[1].y, X[0].y + X[1].x);
         if (k > 0 && k < NF / 2) sa[NF - k] = make_float2(X[0].x + X[1].y, -X[0].y + X[1].x);
     }
-    const cpx* z = fft_lds(sa, sb, NF, 9, tw, true);
+    const cpx* z = fft_lds_t<9, true>(sa, sb, tw);
     for (int i = threadIdx.x; i < NF; i += 256) {
         const cpx v = z[i];
         frames[((size_t)b * T + t0) * NF + i] = v.x * (1.f / NF);
@@ -291,7 +359,7 @@ __global__ __launch_bounds__(256) void mask_istft_bwd_kernel(const float* __rest
         }
         sa[i] = make_float2(v[0], v[1]);
     }
-    const cpx* Z = fft_lds(sa, sb, NF, 9, tw, false);
+    const cpx* Z = fft_lds_t<9, false>(sa, sb, tw);
     for (int k = threadIdx.x; k < BINS; k += 256) {
         cpx G[2];
         split_pair(Z, k, NF, G[0], G[1]);
@@ -380,7 +448,7 @@ __global__ __launch_bounds__(256) void stft_loss_fwd_kernel(const float* __restr
     const float* xb = x + (size_t)b * L;
     const float* yb = y + (size_t)b * L;
     stft_stage_frame<NI, false>(sa, stw, xb, yb, win, tw, f, hop, n, L);
-    const cpx* Z = fft_lds(sa, sb, n, logn, stw, false);
+    const cpx* Z = fft_lds_ni<NI, false>(sa, sb, n, logn, stw);
     float s1 = 0.f, s2 = 0.f, s3 = 0.f;
     for (int k = threadIdx.x; k <= n / 2; k += 256) {
         cpx X, Y;
@@ -418,7 +486,7 @@ __global__ __launch_bounds__(256) void stft_mag_kernel(const float* __restrict__
     const float* xb = x + (size_t)b * L;
     const float* yb = y + (size_t)b * L;
     stft_stage_frame<NI, false>(sa, stw, xb, yb, win, tw, f, hop, n, L);
-    const cpx* Z = fft_lds(sa, sb, n, logn, stw, false);
+    const cpx* Z = fft_lds_ni<NI, false>(sa, sb, n, logn, stw);
     const size_t base = ((size_t)b * nframes + f) * (n / 2 + 1);
     for (int k = threadIdx.x; k <= n / 2; k += 256) {
         cpx X, Y;
@@ -475,7 +543,7 @@ __global__ __launch_bounds__(256) void stft_bwd_kernel(const float* __restrict__
     const float* xb = x + (size_t)b * L;
     const float* yb = MAG ? xb : y + (size_t)b * L;
     stft_stage_frame<NI, MAG>(sa, stw, xb, yb, win, tw, f, hop, n, L);
-    cpx* Z = fft_lds(sa, sb, n, logn, stw, false);
+    cpx* Z = fft_lds_ni<NI, false>(sa, sb, n, logn, stw);
     cpx* other = (Z == sa) ? sb : sa;
     const float c_sc = MAG ? 0.f : coef[0], c_mag = MAG ? 0.f : coef[1];
     const float* gm_row = MAG ? gmag + ((size_t)b * gridDim.x + f) * (n / 2 + 1) : nullptr;
@@ -502,7 +570,7 @@ __global__ __launch_bounds__(256) void stft_bwd_kernel(const float* __restrict__
         }
         other[k] = G;
     }
-    const cpx* g = fft_lds(other, Z, n, logn, stw, true);
+    const cpx* g = fft_lds_ni<NI, true>(other, Z, n, logn, stw);
     float* fo = fr + ((size_t)b * gridDim.x + f) * wl;
     for (int i = threadIdx.x; i < wl; i += 256) fo[i] = win[left + i] * g[left + i].x;
 }
