@@ -1034,45 +1034,56 @@ __global__ void to_fl_kernel(const u32x4* __restrict__ x, float* __restrict__ y,
 
 // (N, C, L) fp32 of the module API <-> ONE octet [L][NP][8] (C <= 8: the network input, its output and the output's cotangent):
 // one pass through a 32 x 32 (frame, position) LDS tile per channel instead of a frames-last fp32 intermediate
+// (N, C, L) fp32 <-> octets [L][NP][8] bf16 (network input / output / cotangent).  The two layouts are transposes of each other
+// (positions contiguous in one, frames in the other): a tile of 64 positions x 16 frames goes through LDS as packed octets,
+// so the fp32 side moves 256-byte row pieces (a wave = 64 consecutive positions of one (frame, channel) row) and the octet
+// side 256-byte pieces (16 frames x 16 bytes).  (Round 3: the first version moved 128-byte pieces through an fp32 tile of
+// 32 x 32 x 8 and ran at 1.1 TB/s.)
 __global__ __launch_bounds__(256) void from_ncl_kernel(const float* __restrict__ x, u32x4* __restrict__ y, int N, int C, int L,
                                                        int NP) {
-    __shared__ float t[8][32][33];
-    const int n0 = blockIdx.x * 32, l0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int cc = 0; cc < 8; ++cc)
-        for (int i = ty; i < 32; i += 8) {
-            const int n = n0 + i, l = l0 + tx;
-            t[cc][i][tx] = (cc < C && n < N && l < L) ? x[((size_t)n * C + cc) * L + l] : 0.f;
-        }
-    __syncthreads();
-    for (int i = ty; i < 32; i += 8) {
-        const int l = l0 + i, n = n0 + tx;
-        if (l < L && n < NP) {
-            float f[8];
+    __shared__ u32x4 t[64][17];
+    const int n0 = blockIdx.x * 16, l0 = blockIdx.y * 64;
+    const int lx = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
-            for (int cc = 0; cc < 8; ++cc) f[cc] = t[cc][tx][i];
-            y[(size_t)l * NP + n] = bf_pack8(f);
-        }
+    for (int k = 0; k < 4; ++k) {
+        const int nn = w + 4 * k, n = n0 + nn, l = l0 + lx;
+        float f[8];
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) f[cc] = (cc < C && n < N && l < L) ? x[((size_t)n * C + cc) * L + l] : 0.f;
+        t[lx][nn] = bf_pack8(f);
+    }
+    __syncthreads();
+    const int nx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int l = l0 + ly + 16 * k, n = n0 + nx;
+        if (l < L && n < NP) y[(size_t)l * NP + n] = t[ly + 16 * k][nx];
     }
 }
 __global__ __launch_bounds__(256) void to_ncl_kernel(const u32x4* __restrict__ y, float* __restrict__ x, int N, int C, int L,
                                                      int NP) {
-    __shared__ float t[8][32][33];
-    const int n0 = blockIdx.x * 32, l0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int i = ty; i < 32; i += 8) {
-        const int l = l0 + i, n = n0 + tx;
-        float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (l < L && n < NP) bf_unpack8(y[(size_t)l * NP + n], f);
+    __shared__ u32x4 t[64][17];
+    const int n0 = blockIdx.x * 16, l0 = blockIdx.y * 64;
+    const int nx = threadIdx.x & 15, ly = threadIdx.x >> 4;
 #pragma unroll
-        for (int cc = 0; cc < 8; ++cc) t[cc][tx][i] = f[cc];
+    for (int k = 0; k < 4; ++k) {
+        const int l = l0 + ly + 16 * k, n = n0 + nx;
+        const u32x4 z4 = {0u, 0u, 0u, 0u};
+        t[ly + 16 * k][nx] = (l < L && n < NP) ? y[(size_t)l * NP + n] : z4;
     }
     __syncthreads();
-    for (int cc = 0; cc < C; ++cc)
-        for (int i = ty; i < 32; i += 8) {
-            const int n = n0 + i, l = l0 + tx;
-            if (n < N && l < L) x[((size_t)n * C + cc) * L + l] = t[cc][i][tx];
+    const int lx = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int nn = w + 4 * k, n = n0 + nn, l = l0 + lx;
+        float f[8];
+        bf_unpack8(t[lx][nn], f);
+        if (n < N && l < L) {
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc)
+                if (cc < C) x[((size_t)n * C + cc) * L + l] = f[cc];
         }
+    }
 }
 
 }  // namespace
@@ -1082,13 +1093,13 @@ __global__ __launch_bounds__(256) void to_ncl_kernel(const u32x4* __restrict__ y
 extern "C" int trunet_bf16_from_ncl(const float* x, void* y, int N, int C, int L, int NP, void* stream) {
     if (!x || !y || N <= 0 || NP < N || L <= 0) return TRUNET_EINVAL;
     if (C <= 0 || C > 8) return TRUNET_ENOTSUP;
-    hipLaunchKernelGGL(from_ncl_kernel, dim3((NP + 31) / 32, (L + 31) / 32), dim3(256), 0, ST, x, (u32x4*)y, N, C, L, NP);
+    hipLaunchKernelGGL(from_ncl_kernel, dim3((NP + 15) / 16, (L + 63) / 64), dim3(256), 0, ST, x, (u32x4*)y, N, C, L, NP);
     return trunet_launch_status();
 }
 extern "C" int trunet_bf16_to_ncl(const void* y, float* x, int N, int C, int L, int NP, void* stream) {
     if (!x || !y || N <= 0 || NP < N || L <= 0) return TRUNET_EINVAL;
     if (C <= 0 || C > 8) return TRUNET_ENOTSUP;
-    hipLaunchKernelGGL(to_ncl_kernel, dim3((NP + 31) / 32, (L + 31) / 32), dim3(256), 0, ST, (const u32x4*)y, x, N, C, L, NP);
+    hipLaunchKernelGGL(to_ncl_kernel, dim3((NP + 15) / 16, (L + 63) / 64), dim3(256), 0, ST, (const u32x4*)y, x, N, C, L, NP);
     return trunet_launch_status();
 }
 
