@@ -106,7 +106,6 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(const trunet_bgemm_args a
     const int total = a.P * nfc;
     const int vb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);      // XCD-contiguous numbering
     const int moct = (a.M + 7) >> 3;
-    (void)moct;
 
     // statistics: per tile the 16 values of a row tile are summed over the 64 frames of the tile (two column blocks in
     // registers, then a butterfly over the 32 lanes that leaves value r(c) in lane c: 1 live register instead of 16)
@@ -126,6 +125,23 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(const trunet_bgemm_args a
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][cb][r] = 0.f;
 
+        // epilogue operands (ReLU-mask source, gradient to accumulate onto) requested BEFORE the k loop: at their point of
+        // use they were eight dependent HBM round trips per tile (one per 4-row group), the whole time of the thin
+        // data-gradient launches (K = 8: decoder.5)
+        u32x2 zpre[NRT][4][BG_NCB], opre[NRT][4][BG_NCB];
+        if (has(TRUNET_EPI_MASK) || has(TRUNET_EPI_ACCUM)) {
+#pragma unroll
+            for (int t = 0; t < NRT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int cb = 0; cb < BG_NCB; ++cb) {
+                        const int og = min((rt0 + t) * 4 + g, moct - 1);                 // rows past M: a valid octet, unused
+                        const size_t eidx = (((size_t)og * a.out_L + p + a.out_pos_off) * a.NP + n0 + 32 * cb + c) * 2 + h;
+                        if (has(TRUNET_EPI_MASK)) zpre[t][g][cb] = ((const u32x2*)a.zmask)[eidx];
+                        if (has(TRUNET_EPI_ACCUM)) opre[t][g][cb] = ((const u32x2*)a.out)[eidx];
+                    }
+        }
         for (int s = 0; s < a.nseg; ++s) {
             const trunet_bseg& sg = a.seg[s];
             const BSegPos sp = bseg_pos(sg, p);
@@ -213,11 +229,11 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(const trunet_bgemm_args a
 #pragma unroll
                     for (int i = 0; i < 4; ++i) val[i] = acc[t][cb][4 * g + i] + bv[i];
                     if (has(TRUNET_EPI_ACCUM)) {
-                        const u32x2 o = ((const u32x2*)a.out)[eidx];
+                        const u32x2 o = opre[t][g][cb];
                         val[0] += bf_lo(o[0]); val[1] += bf_hi(o[0]); val[2] += bf_lo(o[1]); val[3] += bf_hi(o[1]);
                     }
                     if (has(TRUNET_EPI_MASK)) {
-                        const u32x2 zz = ((const u32x2*)a.zmask)[eidx];
+                        const u32x2 zz = zpre[t][g][cb];
                         zv[0] = bf_lo(zz[0]); zv[1] = bf_hi(zz[0]); zv[2] = bf_lo(zz[1]); zv[3] = bf_hi(zz[1]);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) val[i] = (fmaf(e0v[i], zv[i], e1v[i]) > 0.f) ? val[i] : 0.f;
