@@ -140,7 +140,8 @@ enum { TRUNET_DG_STORE = 1,  /* write the data gradient of this segment to `out`
        TRUNET_DG_ACCUM = 8   /* add the value already stored in `out` before masking       */ };
 typedef struct {
     float* out;            /* [nchan][seg.L][NP] */
-    const float* zmask;    /* raw tensor of the source, same shape */
+    const float* zmask;    /* raw tensor of the source, same shape: must BE the segment's src0 (the kernel takes the mask
+                              and the statistics' z from the rows it has staged; anything else: TRUNET_ENOTSUP) */
     const float* e2;       /* per-channel mean of the source's BatchNorm (STATS) */
     float* partials;       /* [trunet_pw_bwd_nparts()][nchan][2], zero-filled by the call */
     int32_t flags; int32_t _pad;

@@ -110,6 +110,48 @@ def test_forward_backward_vs_oracle_f64(N):
     assert float(np.median(errs)) < 2.5e-2, float(np.median(errs))
 
 
+def test_zero_batchnorm_weights_vs_oracle_f64():
+    """pw_bwd_kernel takes the ReLU mask and the z of the source's BatchNorm-backward sums from the ACTIVATION it has
+    staged in LDS (a = c0 z + c1 where a > 0, z = (a - c1) / c0) instead of reading the source a second time.  A
+    BatchNorm weight of exactly zero (c0 = 0) leaves no z in a: those channels take the kernel's slow path (z from
+    global memory).  Zeroed here: single channels and a whole 32-channel row tile of BatchNorms that feed the
+    128 -> 128 encoder layers and the 64 + 128 -> 64 decoder layers; every gradient (the zeroed weights' own first)
+    against the fp64 oracle."""
+    from oracle import network_ref as nr, weights as W
+    N = 126
+    ref, net = _nets(4, seed=5)
+    refd = W.fill_state_dict(nr.TRUNet(input_size=4), seed=5).double()
+    zeroed = {"encoder.1.DepthwiseSeparableConv1d.4.weight": list(range(32, 64)),
+              "encoder.2.DepthwiseSeparableConv1d.4.weight": [5, 77],
+              "encoder.4.DepthwiseSeparableConv1d.4.weight": [127],
+              "decoder.1.TrCNN.4.weight": [3, 40],
+              "decoder.3.TrCNN.4.weight": [63]}
+    with torch.no_grad():
+        for m in (refd, net):
+            pd = dict(m.named_parameters())
+            for pn, idx in zeroed.items():
+                pd[pn][idx] = 0.0
+    x = torch.tensor(np.random.default_rng(N).standard_normal((N, 4, 257)) * 0.5, dtype=torch.float32)
+    cot = torch.tensor(np.random.default_rng(N + 1).standard_normal((N, 8, 257)), dtype=torch.float32)
+    refd.train(); net.train()
+    yd = refd(x.double()); (yd * cot.double()).sum().backward()
+    y = net(x.cuda()); (y * cot.cuda()).sum().backward()
+    assert _rel(y, yd) < 1e-4
+    pd = dict(refd.named_parameters())
+    errs = []
+    for pn, p in net.named_parameters():
+        if pn.startswith("TGRU"):
+            continue
+        _grad_close(p.grad, pd[pn].grad, pn, errs)
+        if pn in zeroed:
+            g, r = p.grad.detach().double().cpu(), pd[pn].grad
+            idx = zeroed[pn]
+            if len(idx) > 8:      # (a single channel with beta <= 0 is masked out altogether: gradient exactly zero)
+                assert float(r[idx].abs().max()) > 1e-2 * float(r.abs().max()), pn      # zeroed channels do have a gradient
+            assert float((g[idx] - r[idx]).abs().max()) < 5e-2 * float(r.abs().max()), (pn, g[idx], r[idx])
+    assert float(np.median(errs)) < 2.5e-2, float(np.median(errs))
+
+
 def test_state_dict_keys_match_reference_layout():
     from oracle import network_ref as nr
     from tinyrecurrentunet_amd import network as hn

@@ -8,7 +8,11 @@
 //   statistics = sum g_s, sum g_s (z_s - mean_s)               (BatchNorm backward of the source)
 // The separate conv_gemm (data gradient) + conv_wgrad launches read dy and z_y twice and z_s twice; this kernel
 // reads each once (7 tensor passes -> 4), which is what bounds the layer at 128 channels (measured 3.7 TB/s in
-// both of the separate kernels).
+// both of the separate kernels).  "Once" includes the ReLU mask and the z_s of the statistics: the data-gradient waves
+// read the staged activation a_s back from the slot in the MFMA C layout (mask = a_s > 0; where a_s > 0,
+// z_s - mean = a_s / c0 - (c1 / c0 + mean)) -- until round 3 they loaded z_s from global memory a second time, two to
+// three tiles after the DMA, and most of those loads missed the L2 (PMC: 3.07 KB per (position, frame) against 2.56
+// algorithmic at 128 channels).  A channel with c0 == 0 (BatchNorm weight exactly zero) takes a slow path.
 //
 // Tile = one position p x 32 frames of every operand row, delivered by LDS-DMA into a ring of NB slots exactly as
 // in conv_wgrad_kernel (rows of 128 B, 16-byte pieces XOR-swizzled through the per-lane SOURCE address; the
@@ -59,6 +63,13 @@ __device__ __forceinline__ void pwb_wait_vmcnt(int n) {
 
 // swizzled float offset of 16-byte piece `pc` (0..7) of row `r` inside a slot
 __device__ __forceinline__ int pwb_off(int r, int pc) { return r * WFC + 4 * (pc ^ ((r >> 1) & 7)); }
+// The data-gradient epilogue reads its 32x32 tile of a source back from the slot in the MFMA C layout: lane (h, c), register
+// r <-> row rb + 4h + ml(r), ml = (r & 3) + 8 (r >> 2), frame c; rb is a multiple of 16, so the row's swizzle term is
+// ((4h + ml) >> 1) & 7 = 2h ^ kr with the compile-time kr = ((r & 3) >> 1) + 4 ((r >> 2) & 1): four per-lane offsets
+// e0 ^ 4 kr, e0 = pwb_e0(h, c), next to immediate row offsets.
+__device__ __forceinline__ int pwb_e0(int h, int c) { return 4 * ((c >> 2) ^ (2 * h)) + (c & 3); }
+__device__ __forceinline__ int pwb_erow(int r) { return ((r & 3) + 8 * (r >> 2)) * WFC; }
+__device__ __forceinline__ int pwb_ekr(int r) { return 4 * (((r & 3) >> 1) + 4 * ((r >> 2) & 1)); }
 
 struct PSegPos { bool valid; int q; };
 __device__ __forceinline__ PSegPos pwb_seg_pos(const trunet_seg& sg, int p) {
@@ -104,6 +115,7 @@ __device__ __forceinline__ T* pwb_uniform(T* p) { return (T*)pwb_uniform((size_t
 // one data-gradient row tile of a wave: what is fixed for the kernel ...
 struct DUnit {
     int seg, ct, cb, flags, mask, phase, share;   // segment, 32-channel tile in it, coefficient base, TRUNET_DG_*
+    bool zero;                                    // statistics asked and some channel's BatchNorm weight is exactly zero
 };
 // ... and what changes with the position p
 struct DRun {
@@ -112,6 +124,7 @@ struct DRun {
     float* ob;            // same element of the data-gradient output
     size_t dstride;       // elements between consecutive channels
     int voff;             // per-lane byte offset: 4h channels down, frame c
+    int lrow;             // this lane's first row (channel 32*ct + 4h) of the source as staged in an LDS slot
 };
 
 // AK: k-pairs of the data-gradient A fragments = padded dz rows / 2 (32 for M <= 64, 64 for M <= 128)
@@ -143,7 +156,8 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
     f32x4* CB = CA + MA;                                     // [sum nchan] (c0, c1, lo, mean) of the sources
     int ntot_ = 0;
     for (int s = 0; s < a.nseg; ++s) ntot_ += a.seg[s].nchan;
-    float* XB = (float*)(CB + ntot_);                        // KSPLIT: [tile parity][row tile][sender half][8][64] floats
+    f32x2* CZ = (f32x2*)(CB + ntot_);                        // [sum nchan] (1/c0, c1/c0 + mean): z - mean = a/c0 - (c1/c0 + mean)
+    float* XB = (float*)(CZ + ntot_);                        // KSPLIT: [tile parity][row tile][sender half][8][64] floats
 
     for (int r = tid; r < MA; r += 512) {
         const int ch = min(r, a.M - 1) + a.a_m_off;
@@ -161,6 +175,10 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
                 f32x4 k = {on ? sg.c0[ci] : 1.f, on ? sg.c1[ci] : 0.f, on ? 0.f : -3.0e38f,
                            ((dg.flags & TRUNET_DG_STATS) && dg.e2) ? dg.e2[ci] : 0.f};
                 CB[base + ci] = k;
+                // a BatchNorm weight of exactly zero: a = c1 does not carry z; the epilogue then reads z for that channel
+                const float ic0 = fabsf(k[0]) >= 1e-30f ? 1.f / k[0] : 0.f;
+                f32x2 kz = {ic0, fmaf(k[1], ic0, k[3])};
+                CZ[base + ci] = kz;
             }
             base += sg.nchan;
         }
@@ -427,6 +445,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
         // =================== data-gradient role (no DMA, no prologue pass: LDS reads, MFMAs, epilogue)
         // (s_setprio 1 for these waves was measured: 4 % slower at 128 channels, neutral at 64)
         const int j = wave - 4;
+        const int e0 = pwb_e0(h, c);
         if constexpr (KSPLIT) {
             constexpr int AH = AK / 2;                 // k-pairs per wave
             const int rt = j & 1, kh = j >> 1;         // row tile, K half (uniform)
@@ -446,6 +465,8 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
             useg = pwb_uniform(useg); uct = pwb_uniform(uct); ucb = pwb_uniform(ucb);
             const int uflags = pwb_uniform(A.dg[useg].flags);
             const trunet_seg& usg = a.seg[useg];
+            // some channel of this row tile has a BatchNorm weight of exactly zero (statistics: slow path below)
+            const bool uzero = (uflags & TRUNET_DG_STATS) && __builtin_amdgcn_ballot_w64(CZ[ucb + 32 * uct + c][0] == 0.f) != 0;
             float af[AH];
             {
                 const int ch = 32 * uct + c;
@@ -462,7 +483,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
 #pragma unroll
             for (int i = 0; i < 8; ++i) { sa1[i] = 0.f; sa2[i] = 0.f; }
             const int rowsel = 16 * kh;               // this wave finishes rows (i & 3) + 8 (i >> 2) + 16 kh + 4 h of the tile
-            const f32x4* CBs = CB + ucb + 32 * uct + 4 * h + rowsel;
+            const f32x2* CZs = CZ + ucb + 32 * uct + 4 * h + rowsel;
             int t0 = t_begin;
             while (t0 < t_end) {
                 const int pi = t0 / nfc;
@@ -470,6 +491,10 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
                 const int t1 = min(t_end, (pi + 1) * nfc);
                 const PSegPos sp = pwb_seg_pos(usg, p);
                 const bool pvalid = sp.valid && (uflags & TRUNET_DG_STORE);
+                int lrow = DZR + 32 * uct + rowsel + 4 * h;        // this lane's first source row in a slot
+#pragma unroll
+                for (int s = 0; s < TRUNET_MAX_SEG; ++s)
+                    if (s < useg && pwb_seg_pos(a.seg[s], p).valid) lrow += (a.seg[s].nchan + 31) & ~31;
                 const size_t dstride = pwb_uniform((size_t)usg.L * a.NP);
                 const size_t o0 = ((size_t)(32 * uct + rowsel) * usg.L + (sp.valid ? sp.q : 0)) * a.NP;
                 const __amdgpu_buffer_rsrc_t rz = pwb_rsrc(pwb_uniform(A.dg[useg].zmask ? A.dg[useg].zmask + o0 : A.dg[useg].out + o0));
@@ -490,9 +515,9 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
                     if (pvalid) {
 #pragma unroll
                         for (int i = 0; i < 8; ++i) { zv[i] = 0.f; ov[i] = 0.f; }
-                        if ((uflags & TRUNET_DG_MASK) && !(PWB_ABL & 1)) {
+                        if (uflags & TRUNET_DG_MASK) {        // the source's activation a = max(c0 z + c1, lo) as staged in the slot
 #pragma unroll
-                            for (int i = 0; i < 8; ++i) zv[i] = pwb_bload(rz, voff, ((i & 3) + 8 * (i >> 2)) * rowb + nb);
+                            for (int i = 0; i < 8; ++i) zv[i] = S[lrow * WFC + pwb_erow(i) + (e0 ^ pwb_ekr(i))];
                         }
                         if ((uflags & TRUNET_DG_ACCUM) && !(PWB_ABL & 1)) {
 #pragma unroll
@@ -516,23 +541,30 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
                     asm volatile("" ::: "memory");
                     if (pvalid) {
                         const bool fin = n0 + c < a.N;
+                        auto rows8 = [&](auto ZGc) __attribute__((always_inline)) {
+                            constexpr bool ZG = decltype(ZGc)::value;      // as in the general path below
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const int ml = (i & 3) + 8 * (i >> 2);
-                            float val = (kh ? dacc[8 + i] : dacc[i]) + xs[((1 - kh) * 8 + i) * 64 + lane];
-                            if (uflags & TRUNET_DG_ACCUM) val += ov[i];
-                            f32x4 k = {0.f, 0.f, 0.f, 0.f};
-                            if (uflags & TRUNET_DG_MASK) {
-                                k = CBs[ml];
-                                val = (fmaf(k[0], zv[i], k[1]) > 0.f) ? val : 0.f;
+                            for (int i = 0; i < 8; ++i) {
+                                const int ml = (i & 3) + 8 * (i >> 2);
+                                float val = (kh ? dacc[8 + i] : dacc[i]) + xs[((1 - kh) * 8 + i) * 64 + lane];
+                                if (uflags & TRUNET_DG_ACCUM) val += ov[i];
+                                if (uflags & TRUNET_DG_MASK) val = (zv[i] > 0.f) ? val : 0.f;
+                                if (!(PWB_ABL & 2)) pwb_bstore(ro, voff, ml * rowb + nb, val);
+                                if (uflags & TRUNET_DG_STATS) {
+                                    const float x = fin ? val : 0.f;
+                                    const f32x2 kz = CZs[ml];
+                                    sa1[i] += x;
+                                    float zc = fmaf(zv[i], kz[0], -kz[1]);      // z - mean, z from a = c0 z + c1 (where a > 0)
+                                    if (ZG) {
+                                        const float z = pwb_bload(rz, voff, ml * rowb + nb);
+                                        if (kz[0] == 0.f) zc = z - kz[1];
+                                    }
+                                    sa2[i] = fmaf(x, zc, sa2[i]);
+                                }
                             }
-                            if (!(PWB_ABL & 2)) pwb_bstore(ro, voff, ml * rowb + nb, val);
-                            if (uflags & TRUNET_DG_STATS) {
-                                const float x = fin ? val : 0.f;
-                                sa1[i] += x;
-                                sa2[i] = fmaf(x, zv[i] - k[3], sa2[i]);
-                            }
-                        }
+                        };
+                        if (uzero) rows8(std::true_type());
+                        else rows8(std::false_type());
                     }
                     slot = (slot + 1 == NB) ? 0 : slot + 1;
                 }
@@ -572,6 +604,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
             }
             if (u.seg >= 0) u.flags = A.dg[u.seg].flags;
             u.seg = pwb_uniform(u.seg); u.ct = pwb_uniform(u.ct); u.cb = pwb_uniform(u.cb); u.flags = pwb_uniform(u.flags);
+            u.zero = (u.flags & TRUNET_DG_STATS) && __builtin_amdgcn_ballot_w64(CZ[u.cb + 32 * u.ct + c][0] == 0.f) != 0;
             return u;
         };
         auto load_af = [&](const DUnit& u, float (&af)[AK]) __attribute__((always_inline)) {
@@ -588,11 +621,16 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
         };
         auto begin_unit = [&](const DUnit& u, int p) __attribute__((always_inline)) {
             DRun r;
-            r.valid = false; r.zb = nullptr; r.ob = nullptr; r.dstride = 0; r.voff = 0;
+            r.valid = false; r.zb = nullptr; r.ob = nullptr; r.dstride = 0; r.voff = 0; r.lrow = 0;
             if (u.seg >= 0 && (u.flags & TRUNET_DG_STORE)) {
                 const trunet_seg& sg = a.seg[u.seg];
                 const PSegPos sp = pwb_seg_pos(sg, p);
                 r.valid = sp.valid;
+                int lr = DZR + 32 * u.ct + 4 * h;           // the slot holds the segments valid at p, in order
+#pragma unroll
+                for (int s = 0; s < TRUNET_MAX_SEG; ++s)
+                    if (s < u.seg && pwb_seg_pos(a.seg[s], p).valid) lr += (a.seg[s].nchan + 31) & ~31;
+                r.lrow = lr;
                 r.dstride = pwb_uniform((size_t)sg.L * a.NP);
                 const size_t o = ((size_t)(32 * u.ct) * sg.L + (sp.valid ? sp.q : 0)) * a.NP;
                 r.zb = pwb_uniform(A.dg[u.seg].zmask + o);
@@ -608,15 +646,14 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
         // dz rows
         auto dgrad_head = [&](const DUnit& u, const DRun& dr, const float (&af)[AK], const float* S, int n0)
                               __attribute__((always_inline)) {
-            const __amdgpu_buffer_rsrc_t rz = pwb_rsrc(pwb_uniform(dr.zb));
             const __amdgpu_buffer_rsrc_t ro = pwb_rsrc(pwb_uniform(dr.ob));
             const int rowb = (int)(pwb_uniform(dr.dstride) * sizeof(float));      // bytes between channels
             const int nb = n0 * (int)sizeof(float);
 #pragma unroll
             for (int r = 0; r < 16; ++r) { zv[r] = 0.f; ov[r] = 0.f; }
-            if ((u.flags & TRUNET_DG_MASK) && !(PWB_ABL & 1)) {
+            if (u.flags & TRUNET_DG_MASK) {       // the source's activation a = max(c0 z + c1, lo) as staged in the slot
 #pragma unroll
-                for (int r = 0; r < 16; ++r) zv[r] = pwb_bload(rz, dr.voff, ((r & 3) + 8 * (r >> 2)) * rowb + nb);
+                for (int r = 0; r < 16; ++r) zv[r] = S[dr.lrow * WFC + pwb_erow(r) + (e0 ^ pwb_ekr(r))];
             }
             if ((u.flags & TRUNET_DG_ACCUM) && !(PWB_ABL & 1)) {
 #pragma unroll
@@ -639,26 +676,35 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
             const __amdgpu_buffer_rsrc_t ro = pwb_rsrc(pwb_uniform(dr.ob));
             const int rowb = (int)(pwb_uniform(dr.dstride) * sizeof(float));
             const int nb = n0 * (int)sizeof(float);
-            const f32x4* CBs = CB + u.cb + 32 * u.ct + 4 * h;
+            const f32x2* CZs = CZ + u.cb + 32 * u.ct + 4 * h;
             const bool fin = n0 + c < a.N;
+            // ZG: z of the statistics read from global memory at its point of use (slow; only when a BatchNorm weight is 0)
+            auto rows16 = [&](auto ZGc) __attribute__((always_inline)) {
+                constexpr bool ZG = decltype(ZGc)::value;
+                const __amdgpu_buffer_rsrc_t rz = pwb_rsrc(pwb_uniform(dr.zb));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ml = (r & 3) + 8 * (r >> 2);
-                if ((r & 3) == 0) asm volatile("" ::: "memory");   // coefficient reads: four rows at a time
-                float val = dacc[r];
-                if (FL & TRUNET_DG_ACCUM) val += ov[r];
-                f32x4 k = {0.f, 0.f, 0.f, 0.f};
-                if (FL & TRUNET_DG_MASK) {
-                    k = CBs[ml];
-                    val = (fmaf(k[0], zv[r], k[1]) > 0.f) ? val : 0.f;
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = (r & 3) + 8 * (r >> 2);
+                    if ((r & 3) == 0) asm volatile("" ::: "memory");   // coefficient reads: four rows at a time
+                    float val = dacc[r];
+                    if (FL & TRUNET_DG_ACCUM) val += ov[r];
+                    if (FL & TRUNET_DG_MASK) val = (zv[r] > 0.f) ? val : 0.f;
+                    if (!(PWB_ABL & 2)) pwb_bstore(ro, dr.voff, ml * rowb + nb, val);
+                    if (FL & TRUNET_DG_STATS) {
+                        const float x = fin ? val : 0.f;
+                        const f32x2 kz = CZs[ml];
+                        st1[r] += x;
+                        float zc = fmaf(zv[r], kz[0], -kz[1]);            // z - mean, z from a = c0 z + c1 (where a > 0)
+                        if (ZG) {
+                            const float z = pwb_bload(rz, dr.voff, ml * rowb + nb);
+                            if (kz[0] == 0.f) zc = z - kz[1];             // kz[1] = mean for such a channel
+                        }
+                        st2[r] = fmaf(x, zc, st2[r]);
+                    }
                 }
-                if (!(PWB_ABL & 2)) pwb_bstore(ro, dr.voff, ml * rowb + nb, val);
-                if (FL & TRUNET_DG_STATS) {
-                    const float x = fin ? val : 0.f;
-                    st1[r] += x;
-                    st2[r] = fmaf(x, zv[r] - k[3], st2[r]);
-                }
-            }
+            };
+            if ((FL & TRUNET_DG_STATS) && u.zero) rows16(std::true_type());
+            else rows16(std::false_type());
         };
         float sa1[16], sa2[16];
 #pragma unroll
@@ -782,6 +828,8 @@ extern "C" int trunet_pw_bwd(const trunet_pwbwd_args* H, void* stream) {
         if (sg.mode == TRUNET_PRO_BNRELU && (!sg.c0 || !sg.c1)) return TRUNET_EINVAL;
         if (!(dg.flags & TRUNET_DG_STORE) || !dg.out) return TRUNET_ENOTSUP;
         if ((dg.flags & TRUNET_DG_MASK) && !dg.zmask) return TRUNET_EINVAL;
+        // the ReLU mask (and z of the statistics) is taken from the source rows the kernel has staged in LDS anyway
+        if ((dg.flags & TRUNET_DG_MASK) && dg.zmask != sg.src0) return TRUNET_ENOTSUP;
         if ((dg.flags & TRUNET_DG_STATS) && (!(dg.flags & TRUNET_DG_MASK) || !dg.partials)) return TRUNET_EINVAL;
         if ((dg.flags & TRUNET_DG_ACCUM) && !(dg.flags & TRUNET_DG_MASK)) return TRUNET_ENOTSUP;
         // the epilogue addresses rows as 32-bit byte offsets from a per-(row tile, position) base
@@ -823,7 +871,7 @@ extern "C" int trunet_pw_bwd(const trunet_pwbwd_args* H, void* stream) {
     }
     const int rows = 2 * MA + ntot;
     const size_t slot = (size_t)rows * WFC * sizeof(float);
-    const size_t fixed = (size_t)(MA + ntot) * sizeof(f32x4) + (ksplit ? 2 * 2 * 2 * 8 * 64 * sizeof(float) : 0);
+    const size_t fixed = (size_t)(MA + ntot) * sizeof(f32x4) + (size_t)ntot * sizeof(f32x2) + (ksplit ? 2 * 2 * 2 * 8 * 64 * sizeof(float) : 0);
     int NB = (int)((160 * 1024 - fixed) / slot);
     if (NB > 4) NB = 4;
     if (NB < 2) return TRUNET_ENOTSUP;
