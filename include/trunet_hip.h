@@ -233,6 +233,13 @@ int trunet_dwconv_bwd(const float* dy, const float* z, const float* ca, const fl
                       const float* zin, const float* s_in, const float* t_in, const float* mean_in,
                       const float* w, float* dy_in, float* partials_in, float* w_partials,
                       float* b_partials, int C, int K, int S, int Lin, int Lout, int NP, int N, void* stream);
+/* The same without the z operand: z = bias + conv(act(zin), w) is recomputed from the input rows the kernel holds anyway,
+ * in trunet_dwconv_fwd's order of operations (bit for bit the stored tensor): one row pass less over HBM.
+ * TRUNET_ENOTSUP for (K, S, Lin, Lout) outside the sliding-window kernels' shapes: call trunet_dwconv_bwd then. */
+int trunet_dwconv_bwd_rz(const float* dy, const float* bias, const float* ca, const float* cb, const float* cc,
+                         const float* zin, const float* s_in, const float* t_in, const float* mean_in,
+                         const float* w, float* dy_in, float* partials_in, float* w_partials,
+                         float* b_partials, int C, int K, int S, int Lin, int Lout, int NP, int N, void* stream);
 int trunet_dwconv_bwd_nparts(int Lin);
 
 /* Bidirectional GRU recurrence over L positions (nn.GRU, network.py:48,55; torch gate order r,z,n).

@@ -62,3 +62,61 @@ def test_dwconv_forward_backward_vs_fp64(K, S, Lin):
     r = gin[:, :, :N]
     st_ref = torch.stack([r.sum((1, 2)), (r * (zin[:, :, :N].double() - mean[:, None, None].double())).sum((1, 2))], 1)
     assert _l2(part.view(nparts, Cn, 2).double().sum(0), st_ref) < 1e-5
+
+
+@pytest.mark.parametrize("K,S,Lin", [(3, 1, 13), (5, 2, 21), (3, 2, 16), (5, 2, 128), (3, 1, 64), (3, 2, 33), (3, 1, 2), (5, 2, 3)])
+def test_dwconv_backward_with_recomputed_z(K, S, Lin):
+    """trunet_dwconv_bwd_rz (round 3): the backward that recomputes the conv's raw output z from its input rows instead of
+    reading it.  With z = the forward kernel's own output both entry points must agree BIT FOR BIT on the data gradient and the
+    weight / bias gradient sums (same dz, same order), chunk boundaries and ragged lengths included; the z-reading one is
+    pinned against fp64 above.  One channel has a BatchNorm scale of exactly zero (the kernel's re-read path)."""
+    from tinyrecurrentunet_amd import _lib as L
+    from tinyrecurrentunet_amd._lib import check, ptr
+    lib, st = L.lib(), L.stream()
+    g = torch.Generator(device=DEV)
+    g.manual_seed(7 + 100 * K + 10 * S + Lin)
+    rnd = lambda *s: torch.randn(*s, generator=g, device=DEV)
+    N, NP, Cn = 1300, 1536, 24
+    Lout = (Lin + 2 * (K // 2) - K) // S + 1
+    zin = rnd(Cn, Lin, NP)
+    sc, sh, mean = rnd(Cn) * 0.3 + 1, rnd(Cn) * 0.2, rnd(Cn) * 0.1
+    sc[5] = 0.0
+    sh[5] = 0.3
+    wgt, b = rnd(Cn, 1, K) * 0.5, rnd(Cn) * 0.1
+    z = torch.empty(Cn, Lout, NP, device=DEV)
+    part = torch.empty(lib.trunet_dwconv_nparts(Lout) * Cn * 2, device=DEV)
+    check(lib.trunet_dwconv_fwd(ptr(zin), ptr(sc), ptr(sh), ptr(wgt), ptr(b), ptr(z), ptr(part), Cn, K, S, Lin, Lout, NP, N, st), "fwd")
+    dy = rnd(Cn, Lout, NP)
+    ca, cb, cc = rnd(Cn) * 0.5 + 1, rnd(Cn) * 0.1, rnd(Cn) * 0.05
+    nparts = lib.trunet_dwconv_bwd_nparts(Lin)
+    outs = []
+    for rz in (False, True):
+        din = torch.full((Cn, Lin, NP), float("nan"), device=DEV)
+        pr = torch.full((nparts * Cn * 2,), float("nan"), device=DEV)
+        wp = torch.full((nparts * Cn * K,), float("nan"), device=DEV)
+        bp = torch.full((nparts * Cn,), float("nan"), device=DEV)
+        tail = (ptr(ca), ptr(cb), ptr(cc), ptr(zin), ptr(sc), ptr(sh), ptr(mean), ptr(wgt), ptr(din), ptr(pr), ptr(wp), ptr(bp),
+                Cn, K, S, Lin, Lout, NP, N, st)
+        if rz:
+            check(lib.trunet_dwconv_bwd_rz(ptr(dy), ptr(b), *tail), "bwd_rz")
+        else:
+            check(lib.trunet_dwconv_bwd(ptr(dy), ptr(z), *tail), "bwd")
+        torch.cuda.synchronize()
+        outs.append((din, pr, wp, bp))
+    (din0, pr0, wp0, bp0), (din1, pr1, wp1, bp1) = outs
+    assert torch.equal(din0, din1) and torch.equal(wp0, wp1) and torch.equal(bp0, bp1)
+    # statistics: sum g bit for bit; sum g (zin - mean) takes zin - mean from the activation (a / sc - (sh / sc + mean) where
+    # a > 0) instead of the raw row: equal to rounding
+    pr0, pr1 = pr0.view(nparts, Cn, 2), pr1.view(nparts, Cn, 2)
+    assert torch.equal(pr0[:, :, 0], pr1[:, :, 0])
+    assert _l2(pr1[:, :, 1].double().sum(0), pr0[:, :, 1].double().sum(0)) < 1e-5
+
+
+def test_dwconv_backward_rz_refuses_other_shapes():
+    from tinyrecurrentunet_amd import _lib as L
+    from tinyrecurrentunet_amd._lib import ptr
+    lib, st = L.lib(), L.stream()
+    t = torch.zeros(4 * 9 * 128, device=DEV)
+    rc = lib.trunet_dwconv_bwd_rz(ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), ptr(t),
+                                  ptr(t), ptr(t), 4, 5, 1, 9, 9, 128, 100, st)
+    assert rc == L.TRUNET_ENOTSUP

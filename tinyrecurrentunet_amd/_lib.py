@@ -151,6 +151,7 @@ def _declare(L):
         "trunet_dwconv_bwd_nparts": [i],
         "trunet_dwconv_fwd": [p, p, p, p, p, p, p, i, i, i, i, i, i, i, p],
         "trunet_dwconv_bwd": [p] * 14 + [i] * 7 + [p],
+        "trunet_dwconv_bwd_rz": [p] * 14 + [i] * 7 + [p],
         "trunet_gru_fwd": [p, p, p, p, p, p, p, i, i, i, p],
         "trunet_gru_bwd": [p, p, p, p, p, p, p, i, i, i, i, p],
         "trunet_gru_cell": [p, p, p, p, i, i, i, p],

@@ -388,6 +388,139 @@ __global__ __launch_bounds__(256) void dw2_bwd_kernel(
     }
 }
 
+// The same backward WITHOUT reading z (the depthwise conv's own raw output, needed by its BatchNorm backward
+// dz = ca dy + cb z + cc): z[lo] = b + sum_k w[k] a[lo S + k - K/2] is recomputed from the activated input rows, which the
+// kernel holds anyway (mask, weight gradient) -- in dw2_fwd_kernel's order of operations, so it is the stored value bit
+// for bit.  One of the four row passes of the stride-1 layers (dy, z, zin in; dy_in out) goes away for K FMAs per
+// element.  The window of activated (and raw: statistics) input rows leads the group by K/2 + 1 rows:
+//   aw[i] = a[m S + i], i < AW = S + K/2 + 1;   z[m + 1] = b + sum_k w[k] aw[S - K/2 + k]
+// A chunk warms up over two extra groups (dz rows m0 - 1 and m0).  Loads are unconditional on clamped rows (a load inside
+// a branch makes hipcc drain the memory queue in front of it).
+template <int K, int S>
+__global__ __launch_bounds__(256) void dw2_bwd_rz_kernel(
+    const float* __restrict__ dy, const float* __restrict__ bias, const float* __restrict__ ca,
+    const float* __restrict__ cb, const float* __restrict__ cc, const float* __restrict__ zin,
+    const float* __restrict__ s_in, const float* __restrict__ t_in, const float* __restrict__ mean_in,
+    const float* __restrict__ w, float* __restrict__ dy_in, float* __restrict__ partials_in,
+    float* __restrict__ w_partials, float* __restrict__ b_partials, int C, int Lin, int Lout, int NP, int N) {
+    constexpr int LOMIN = -1, W = 3;
+    constexpr int AW = S + K / 2 + 1, ZO = S - K / 2;
+    static_assert((K == 3 && S == 1) || (K == 5 && S == 2) || (K == 3 && S == 2), "window derived for these shapes");
+    __shared__ double red[256];
+    const int c = blockIdx.y;
+    const float a0 = ca[c], a1 = cb[c], a2 = cc[c];
+    const float sc = s_in[c], sh = t_in[c], mu = mean_in[c], bb = bias[c];
+    // the statistics' zin - mean from the activation where it is > 0 (elsewhere the masked gradient is 0): a = sc zin + sh.
+    // sc == 0 (BatchNorm weight exactly zero; uniform over the block): a does not carry zin, the row is read again.
+    const bool sc0 = fabsf(sc) < 1e-30f;
+    const float isc = sc0 ? 0.f : 1.f / sc, zoff = fmaf(sh, isc, mu);
+    float wk[K];
+    double dwk[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { wk[k] = w[c * K + k]; dwk[k] = 0.0; }
+    double db = 0.0, s1 = 0.0, s2 = 0.0;
+    const int G = (Lin + S - 1) / S;
+    const int m0 = (int)(((long long)blockIdx.z * G) / DW2_CH), m1 = (int)(((long long)(blockIdx.z + 1) * G) / DW2_CH);
+    for (int qd = blockIdx.x * 256 + threadIdx.x; qd < NP / 4; qd += DW2_FB * 256) {
+        const int n = 4 * qd;
+        const float* pdy = dy + (size_t)c * Lout * NP + n;
+        const float* pin = zin + (size_t)c * Lin * NP + n;
+        float* pout = dy_in + (size_t)c * Lin * NP + n;
+        f32x4 aw[AW];                   // activated input rows m*S + i
+        auto load_row = [&](int li, f32x4& act) {
+            const bool ok = li >= 0 && li < Lin;
+            const f32x4 raw = DW2_LD(pin + (size_t)min(max(li, 0), Lin - 1) * NP);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) act[j] = ok ? fmaxf(fmaf(raw[j], sc, sh), 0.f) : 0.f;
+        };
+        f32x4 dzw[W];                   // dzw[i] = dz row m + LOMIN + i
+#pragma unroll
+        for (int i = 0; i < W; ++i) dzw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int ms = m0 - 2;          // two warm-up groups: dz rows m0 - 1, m0
+#pragma unroll
+        for (int i = S; i < AW; ++i) load_row(ms * S + i - S, aw[i]);      // pre-shifted: the loop shifts first
+        for (int m = ms; m < m1; ++m) {
+#pragma unroll
+            for (int i = 0; i < AW - S; ++i) aw[i] = aw[i + S];
+#pragma unroll
+            for (int i = AW - S; i < AW; ++i) load_row(m * S + i, aw[i]);
+#pragma unroll
+            for (int i = 0; i < W - 1; ++i) dzw[i] = dzw[i + 1];
+            {
+                const int lo = m + 1;
+                const bool ok = lo >= 0 && lo < Lout;
+                const f32x4 dv = DW2_LD(pdy + (size_t)min(max(lo, 0), Lout - 1) * NP);
+                f32x4 zrec = {bb, bb, bb, bb};
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) zrec[j] = fmaf(wk[k], aw[ZO + k][j], zrec[j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    dzw[W - 1][j] = (ok && n + j < N) ? fmaf(a0, dv[j], fmaf(a1, zrec[j], a2)) : 0.f;
+            }
+            if (m < m0) continue;
+#pragma unroll
+            for (int e = 0; e < S; ++e) {
+                const int li = m * S + e;
+                if (li >= Lin) continue;
+                const f32x4 act = aw[e];
+                f32x4 zc;                                                 // zin - mean
+#pragma unroll
+                for (int j = 0; j < 4; ++j) zc[j] = fmaf(act[j], isc, -zoff);
+                if (sc0) {
+                    const f32x4 zi = DW2_LD(pin + (size_t)li * NP);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) zc[j] = zi[j] - mu;
+                }
+                f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    constexpr int half = K / 2;
+                    const int num = e + half - k;                        // relative to m*S; compile-time after unrolling
+                    if (((num % S) + S) % S != 0) continue;
+                    const int lo_rel = (num >= 0) ? num / S : -((-num) / S);
+                    const int wi = lo_rel - LOMIN;
+                    float rw = 0.f, rb = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float dzv = dzw[wi][j];
+                        g[j] = fmaf(wk[k], dzv, g[j]);
+                        rw = fmaf(dzv, act[j], rw);
+                        rb += dzv;
+                    }
+                    dwk[k] += (double)rw;
+                    if (k == half) db += (double)rb;                      // e == 0 here: every dz row counted once
+                }
+                f32x4 o;
+                float r1 = 0.f, r2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[j] = (act[j] > 0.f) ? g[j] : 0.f;
+                    r1 += o[j];
+                    r2 = fmaf(o[j], zc[j], r2);
+                }
+                s1 += (double)r1;
+                s2 += (double)r2;
+                DW2_ST(pout + (size_t)li * NP, o);
+            }
+        }
+    }
+    const int part = blockIdx.z * DW2_FB + blockIdx.x;
+    double r;
+    r = block_sum_f64(s1, red);
+    if (threadIdx.x == 0) partials_in[((size_t)part * C + c) * 2 + 0] = (float)r;
+    r = block_sum_f64(s2, red);
+    if (threadIdx.x == 0) partials_in[((size_t)part * C + c) * 2 + 1] = (float)r;
+    r = block_sum_f64(db, red);
+    if (threadIdx.x == 0) b_partials[(size_t)part * C + c] = (float)r;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        r = block_sum_f64(dwk[k], red);
+        if (threadIdx.x == 0) w_partials[((size_t)part * C + c) * K + k] = (float)r;
+    }
+}
+
 // ---------------------------------------------------------------- activation backward at a block boundary
 // A stand-alone block class (network.py:9-120) receives the cotangent of its POST-activation output, the fused
 // schedule works on gradients of the BatchNorm output: dy *= [sc[c] z + sh[c] > 0] in place (sc == NULL: [z > 0],
@@ -856,6 +989,29 @@ extern "C" int trunet_dwconv_bwd(const float* dy, const float* z, const float* c
     if (K == 3) hipLaunchKernelGGL(dwconv_bwd_kernel<3>, grid, dim3(256), 0, ST, dy, z, ca, cb, cc, zin, s_in, t_in, mean_in, w, dy_in, partials_in, w_partials, b_partials, C, S, Lin, Lout, NP, N);
     else if (K == 5) hipLaunchKernelGGL(dwconv_bwd_kernel<5>, grid, dim3(256), 0, ST, dy, z, ca, cb, cc, zin, s_in, t_in, mean_in, w, dy_in, partials_in, w_partials, b_partials, C, S, Lin, Lout, NP, N);
     else return TRUNET_ENOTSUP;
+    return trunet_launch_status();
+}
+
+// trunet_dwconv_bwd without the z operand: z is recomputed from (zin, w, bias) as trunet_dwconv_fwd computed it
+// (TRUNET_ENOTSUP for shapes the sliding-window kernels do not cover: call trunet_dwconv_bwd with z then)
+extern "C" int trunet_dwconv_bwd_rz(const float* dy, const float* bias, const float* ca, const float* cb, const float* cc,
+                                    const float* zin, const float* s_in, const float* t_in, const float* mean_in,
+                                    const float* w, float* dy_in, float* partials_in, float* w_partials, float* b_partials,
+                                    int C, int K, int S, int Lin, int Lout, int NP, int N, void* stream) {
+    if (!dy || !bias || !ca || !cb || !cc || !zin || !s_in || !t_in || !mean_in || !w || !dy_in || !partials_in ||
+        !w_partials || !b_partials || (NP % 128))
+        return TRUNET_EINVAL;
+    static const bool off = [] { const char* e = getenv("TRUNET_DW_RZ"); return e && e[0] == '0'; }();
+    if (off || dw_gather_forced() || Lout != (Lin + 2 * (K / 2) - K) / S + 1 ||
+        !((K == 3 && S == 1) || (K == 5 && S == 2) || (K == 3 && S == 2)))
+        return TRUNET_ENOTSUP;
+    const dim3 g2(DW2_FB, C, DW2_CH);
+#define DW2_BWD(KK, SS) hipLaunchKernelGGL((dw2_bwd_rz_kernel<KK, SS>), g2, dim3(256), 0, ST, dy, bias, ca, cb, cc, zin, s_in,  \
+                                           t_in, mean_in, w, dy_in, partials_in, w_partials, b_partials, C, Lin, Lout, NP, N)
+    if (K == 3 && S == 1) DW2_BWD(3, 1);
+    else if (K == 5) DW2_BWD(5, 2);
+    else DW2_BWD(3, 2);
+#undef DW2_BWD
     return trunet_launch_status();
 }
 

@@ -1000,10 +1000,13 @@ class TRUNetEngine:
         part = w.flat("partials_dw", nparts * C * 2)
         wpart = w.flat("dw_w_partials", nparts * C * k)
         bpart = w.flat("dw_b_partials", nparts * C)
-        check(lib.trunet_dwconv_bwd(ptr(dy), ptr(z), ptr(bn.ca), ptr(bn.cb), ptr(bn.cc), ptr(a_pw.t),
-                                    ptr(a_pw.bn.scale), ptr(a_pw.bn.shift), ptr(a_pw.bn.mean),
-                                    ptr(dwc.weight.data), ptr(dy_pw), ptr(part), ptr(wpart), ptr(bpart), C, k, s_,
-                                    a_pw.L, a_dw.L, NP, N, st), "dwconv_bwd")
+        tail = (ptr(bn.ca), ptr(bn.cb), ptr(bn.cc), ptr(a_pw.t), ptr(a_pw.bn.scale), ptr(a_pw.bn.shift), ptr(a_pw.bn.mean),
+                ptr(dwc.weight.data), ptr(dy_pw), ptr(part), ptr(wpart), ptr(bpart), C, k, s_, a_pw.L, a_dw.L, NP, N, st)
+        # z (the depthwise conv's own output) is recomputed from its input rows instead of read: one row pass less
+        rc = lib.trunet_dwconv_bwd_rz(ptr(dy), ptr(dwc.bias.data), *tail)
+        if rc == L.TRUNET_ENOTSUP:
+            rc = lib.trunet_dwconv_bwd(ptr(dy), ptr(z), *tail)
+        check(rc, "dwconv_bwd")
         check(lib.trunet_reduce_partials(self._wg_slot(dwc.weight), ptr(wpart), nparts, C * k, 0, st), "reduce")
         check(lib.trunet_reduce_partials(self._wg_slot(dwc.bias), ptr(bpart), nparts, C, 0, st), "reduce")
         self._bn_bwd(w, a_pw.bn, nparts, grads, part_name="partials_dw")
