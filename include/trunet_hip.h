@@ -475,6 +475,14 @@ int trunet_bf16_dwconv_bwd(const void* dy, const void* z, const float* ca, const
                            const float* s_in, const float* t_in, const float* mean_in, const float* w, void* dy_in,
                            float* partials_in, float* w_partials, float* b_partials, int C, int K, int S, int Lin, int Lout,
                            int NP, int N, void* stream);
+/* The bidirectional GRU recurrence over L positions (trunet_gru_fwd / trunet_gru_bwd; network.py:48,55) on octet tensors:
+ * gi [6H/8][L][NP][8] (both directions' input projections incl. b_ih, torch gate order r, z, n), hout / dhout / dghn
+ * [2H/8][L][NP][8], gates [2][4][H/8][L][NP][8] (r, z, n, W_hn h + b_hn; NULL in eval), dgi like gi.  fp32 MFMAs and an
+ * fp32 carry inside the recurrence; only the tensors in HBM are bf16.  H = 64 (TRUNET_ENOTSUP otherwise). */
+int trunet_bf16_gru_fwd(const void* gi, const float* w_hh, const float* b_hh, const float* w_hh_rev, const float* b_hh_rev,
+                        void* hout, void* gates, int H, int L, int NP, void* stream);
+int trunet_bf16_gru_bwd(const void* dhout, const void* hout, const void* gates, const float* w_hh, const float* w_hh_rev,
+                        void* dgi, void* dghn, int H, int L, int NP, void* stream);
 /* layout changes: frames-last fp32 [C][L][NP] <-> octet bf16 (network input / output and the fp32 bottleneck of the bf16
  * path: FGRU); channels C..8*ceil(C/8)-1 of the octet tensor are written as zeros */
 int trunet_bf16_from_frames_last(const float* x, void* y_oct, int C, int L, int NP, void* stream);

@@ -6,7 +6,8 @@ from tinyrecurrentunet_amd import network as hn, optim, stft_loss as sl, util
 CFG = dict(fft_sizes=[512, 1024, 2048], hop_sizes=[50, 120, 240], win_lengths=[240, 600, 1200], sc_lambda=0.5, mag_lambda=0.5,
            band="full")
 dev = "cuda"
-g = torch.Generator(device=dev); g.manual_seed(3)
+SEED = int(os.environ.get("CURVE_SEED", "0"))
+g = torch.Generator(device=dev); g.manual_seed(3 + SEED)
 B, L = 8, 32000
 c = 0.1 * torch.randn((B, 1, L + 1), generator=g, device=dev)
 clean = (0.5 * (c[..., 1:] + c[..., :-1])).contiguous()
@@ -14,7 +15,7 @@ noisy = (clean + 0.05 * torch.randn((B, 1, L), generator=g, device=dev)).contigu
 mr = sl.MultiResolutionSTFTLoss(**CFG).to(dev)
 curves = {}
 for prec in ("fp32", "bf16"):
-    torch.manual_seed(0)
+    torch.manual_seed(SEED)
     net = hn.TRUNet(input_size=4, precision=prec).to(dev).train()
     opt = optim.FusedAdamW(net.parameters(), lr=float(sys.argv[1]) if len(sys.argv) > 1 else 1e-3)
     ls = []
@@ -25,6 +26,7 @@ for prec in ("fp32", "bf16"):
         opt.step()
         ls.append(float(loss))
     curves[prec] = ls
-for i in range(0, len(curves["fp32"]), 5):
-    print("%3d  fp32 %.4f   bf16 %.4f" % (i, curves["fp32"][i], curves["bf16"][i]))
+step = int(os.environ.get("CURVE_EVERY", "5"))
+for i in range(0, len(curves["fp32"]), step):
+    print("%3d  fp32 %.4f   bf16 %.4f   %+.4f" % (i, curves["fp32"][i], curves["bf16"][i], curves["bf16"][i] / curves["fp32"][i] - 1))
 print("last fp32 %.4f bf16 %.4f" % (curves["fp32"][-1], curves["bf16"][-1]))

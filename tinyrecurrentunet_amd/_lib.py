@@ -194,6 +194,8 @@ def _declare(L):
         "trunet_bf16_dw_nparts": [i, i],
         "trunet_bf16_dwconv_fwd": [p, p, p, p, p, p, p, i, i, i, i, i, i, i, p],
         "trunet_bf16_dwconv_bwd": [p] * 14 + [i] * 7 + [p],
+        "trunet_bf16_gru_fwd": [p, p, p, p, p, p, p, i, i, i, p],
+        "trunet_bf16_gru_bwd": [p, p, p, p, p, p, p, i, i, i, p],
         "trunet_bf16_from_frames_last": [p, p, i, i, i, p],
         "trunet_bf16_from_ncl": [p, p, i, i, i, i, p],
         "trunet_bf16_to_ncl": [p, p, i, i, i, i, p],

@@ -27,6 +27,10 @@ BN_MOM = 0.1
 # Backward of the pointwise convs in front of a BatchNorm: one fused launch (trunet_pw_bwd) instead of
 # trunet_conv_wgrad + trunet_conv_gemm; TRUNET_FUSED_PWBWD=0 keeps the separate launches (A/B measurements).
 FUSED_PWBWD = os.environ.get("TRUNET_FUSED_PWBWD", "1") != "0"
+# Depthwise backward without reading the conv's own output z (trunet_dwconv_bwd_rz recomputes it from the input rows, bit for
+# bit what trunet_dwconv_fwd stored).  "0" / DW_RZ = False: read the stored z -- needed when the saved tensors are NOT this
+# engine's own forward (tests that hand it the bf16 engine's rounded state).
+DW_RZ = os.environ.get("TRUNET_DW_RZ", "1") != "0"
 
 FUSED_THIN = os.environ.get("TRUNET_FUSED_THIN", "0") == "1"
 
@@ -1003,7 +1007,7 @@ class TRUNetEngine:
         tail = (ptr(bn.ca), ptr(bn.cb), ptr(bn.cc), ptr(a_pw.t), ptr(a_pw.bn.scale), ptr(a_pw.bn.shift), ptr(a_pw.bn.mean),
                 ptr(dwc.weight.data), ptr(dy_pw), ptr(part), ptr(wpart), ptr(bpart), C, k, s_, a_pw.L, a_dw.L, NP, N, st)
         # z (the depthwise conv's own output) is recomputed from its input rows instead of read: one row pass less
-        rc = lib.trunet_dwconv_bwd_rz(ptr(dy), ptr(dwc.bias.data), *tail)
+        rc = lib.trunet_dwconv_bwd_rz(ptr(dy), ptr(dwc.bias.data), *tail) if DW_RZ else L.TRUNET_ENOTSUP
         if rc == L.TRUNET_ENOTSUP:
             rc = lib.trunet_dwconv_bwd(ptr(dy), ptr(z), *tail)
         check(rc, "dwconv_bwd")

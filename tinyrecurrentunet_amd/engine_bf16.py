@@ -35,6 +35,8 @@ FUSED_CONVT16 = os.environ.get("TRUNET_BF16_FUSED_CONVT", "1") != "0"
 # The FGRU input projection (M = 384), its data gradient and its weight gradients on the bf16 kernels (the recurrence, its
 # W_hh gradients and the block's pointwise conv stay fp32); TRUNET_BF16_GRU_PROJ=0 keeps the whole block on the fp32 kernels.
 GRU_PROJ16 = os.environ.get("TRUNET_BF16_GRU_PROJ", "1") != "0"
+# the recurrence kernels read and write bf16 octets (trunet_bf16_gru_fwd / _bwd); "0": the fp32 kernels between conversions
+GRU_IO16 = GRU_PROJ16 and os.environ.get("TRUNET_BF16_GRU_IO", "1") != "0"
 # Every packed weight image of a step in one launch at the start of the forward (the plan is learnt during the first
 # step); TRUNET_BF16_BATCH_PACK=0 packs in front of each GEMM instead.
 BATCH_PACK16 = os.environ.get("TRUNET_BF16_BATCH_PACK", "1") != "0"
@@ -317,6 +319,18 @@ class TRUNetEngineBF16(TRUNetEngine):
         torch.cat((gru.weight_ih_l0.data, gru.weight_ih_l0_reverse.data), 0, out=wih)
         torch.cat((gru.bias_ih_l0.data, gru.bias_ih_l0_reverse.data), 0, out=bih)
         Lg = cur.L
+        if GRU_IO16:
+            # gi, the recurrence output and the saved gates as octets: no fp32 tensor and no conversion launch on this path
+            gi16 = self._get16(w, "gi16", 6 * Hh, Lg, NP)
+            for m0 in range(0, 6 * Hh, 128):
+                self._gemm16(w, N=N, NP=NP, P=Lg, M=min(128, 6 * Hh - m0), out=gi16[m0 // 8:], out_L=Lg, W=wih,
+                             ldw_m=gru.input_size, ldw_c=1, segs=[cur.seg()], bias=bih[m0:], w_m_off=m0)
+            hout16 = self._get16(w, "hout16", 2 * Hh, Lg, NP)
+            gates16 = self._get16(w, "gates16", 8 * Hh, Lg, NP) if training else None      # [dir][r, z, n, gh][Hh]
+            check(lib.trunet_bf16_gru_fwd(ptr16(gi16), ptr(gru.weight_hh_l0.data), ptr(gru.bias_hh_l0.data),
+                                          ptr(gru.weight_hh_l0_reverse.data), ptr(gru.bias_hh_l0_reverse.data), ptr16(hout16),
+                                          ptr16(gates16) if training else None, Hh, Lg, NP, L.stream()), "bf16_gru_fwd")
+            return Act16(hout16, 2 * Hh, Lg)
         gi = w.get("gi", (6 * Hh, Lg, NP))
         for m0 in range(0, 6 * Hh, 128):
             self._gemm16(w, N=N, NP=NP, P=Lg, M=min(128, 6 * Hh - m0), out=gi, out_L=Lg, W=wih, ldw_m=gru.input_size, ldw_c=1,
@@ -340,14 +354,21 @@ class TRUNetEngineBF16(TRUNetEngine):
         dhout16 = self._get16(w, "dhout16", 2 * Hh, Lg, NP)
         self._pw_bwd16(w, N=N, NP=NP, P=Lg, M=conv.out_channels, dz=dy, dz1=z, dz_bn=bn, W=conv.weight, bias=conv.bias,
                        segs=[hout16.seg()], outs=[dict(out=dhout16)], grads=grads)
-        dhout = self._to32(w, "dhout", dhout16, 2 * Hh, Lg, NP)
-        dgi = w.get("dgi", (6 * Hh, Lg, NP))
-        dghn = w.get("dghn", (2 * Hh, Lg, NP))
-        gates = w.t["gates"]
-        check(lib.trunet_gru_bwd(ptr(dhout), ptr(hout.t), ptr(gates), ptr(gru.weight_hh_l0.data),
-                                 ptr(gru.weight_hh_l0_reverse.data), ptr(dgi), ptr(dghn), Hh, Lg, NP, N, st), "gru_bwd")
-        dgi16 = self._to16(w, "dgi16", dgi, 6 * Hh, Lg, NP)
-        dghn16 = self._to16(w, "dghn16", dghn, 2 * Hh, Lg, NP)
+        if GRU_IO16:
+            dgi16 = self._get16(w, "dgi16", 6 * Hh, Lg, NP)
+            dghn16 = self._get16(w, "dghn16", 2 * Hh, Lg, NP)
+            check(lib.trunet_bf16_gru_bwd(ptr16(dhout16), ptr16(hout16.t), ptr16(w.t["gates16"]), ptr(gru.weight_hh_l0.data),
+                                          ptr(gru.weight_hh_l0_reverse.data), ptr16(dgi16), ptr16(dghn16), Hh, Lg, NP, st),
+                  "bf16_gru_bwd")
+        else:
+            dhout = self._to32(w, "dhout", dhout16, 2 * Hh, Lg, NP)
+            dgi = w.get("dgi", (6 * Hh, Lg, NP))
+            dghn = w.get("dghn", (2 * Hh, Lg, NP))
+            gates = w.t["gates"]
+            check(lib.trunet_gru_bwd(ptr(dhout), ptr(hout.t), ptr(gates), ptr(gru.weight_hh_l0.data),
+                                     ptr(gru.weight_hh_l0_reverse.data), ptr(dgi), ptr(dghn), Hh, Lg, NP, N, st), "gru_bwd")
+            dgi16 = self._to16(w, "dgi16", dgi, 6 * Hh, Lg, NP)
+            dghn16 = self._to16(w, "dghn16", dghn, 2 * Hh, Lg, NP)
         for d, sfx in enumerate(("", "_reverse")):
             whh = getattr(gru, "weight_hh_l0" + sfx)
             bhh = getattr(gru, "bias_hh_l0" + sfx)
@@ -426,8 +447,10 @@ class TRUNetEngineBF16(TRUNetEngine):
         # FGRU: the recurrence and the block's pointwise conv in fp32
         if GRU_PROJ16:
             hout = acts["hout"] = self._gru16(w, cur, net.FGRU.GRU, N, NP, training)
-            # the block's pointwise conv on the bf16 kernels as well: the recurrence output once more as octets
-            h16 = acts["hout16"] = Act16(self._to16(w, "hout16", hout.t, hout.C, hout.L, NP), hout.C, hout.L)
+            if GRU_IO16:
+                h16 = acts["hout16"] = hout
+            else:   # the block's pointwise conv on the bf16 kernels as well: the recurrence output once more as octets
+                h16 = acts["hout16"] = Act16(self._to16(w, "hout16", hout.t, hout.C, hout.L, NP), hout.C, hout.L)
             cur = acts["fgru"] = self._pw(w, "fgru", [h16], net.FGRU.conv[0], net.FGRU.conv[1], N, NP, training)
         else:
             enc5f = acts["enc5.f32"] = Act(self._to32(w, "z:enc5.f32", cur.t, cur.C, cur.L, NP), cur.C, cur.L, cur.bn)
