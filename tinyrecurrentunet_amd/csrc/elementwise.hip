@@ -412,7 +412,8 @@ __global__ __launch_bounds__(256) void dw2_bwd_rz_kernel(
     const float sc = s_in[c], sh = t_in[c], mu = mean_in[c], bb = bias[c];
     // the statistics' zin - mean from the activation where it is > 0 (elsewhere the masked gradient is 0): a = sc zin + sh.
     // sc == 0 (BatchNorm weight exactly zero; uniform over the block): a does not carry zin, the row is read again.
-    const bool sc0 = fabsf(sc) < 1e-30f;
+    // (precision of a / sc - (sh / sc + mean): eps (|zin| + |sh / sc|); an offset beyond 2^16 times the scale: re-read as well)
+    const bool sc0 = fabsf(sc) < 1e-30f || fabsf(sh) > 65536.f * fabsf(sc);
     const float isc = sc0 ? 0.f : 1.f / sc, zoff = fmaf(sh, isc, mu);
     float wk[K];
     double dwk[K];

@@ -175,8 +175,11 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
                 f32x4 k = {on ? sg.c0[ci] : 1.f, on ? sg.c1[ci] : 0.f, on ? 0.f : -3.0e38f,
                            ((dg.flags & TRUNET_DG_STATS) && dg.e2) ? dg.e2[ci] : 0.f};
                 CB[base + ci] = k;
-                // a BatchNorm weight of exactly zero: a = c1 does not carry z; the epilogue then reads z for that channel
-                const float ic0 = fabsf(k[0]) >= 1e-30f ? 1.f / k[0] : 0.f;
+                // a BatchNorm weight of exactly zero: a = c1 does not carry z; the epilogue then reads z for that channel.
+                // Precision of z - mean = a / c0 - (c1 / c0 + mean): the rounding of a (eps |a|) divided by c0, i.e.
+                // eps (|z| + |c1 / c0|) -- |beta / gamma| times the rounding z itself carries; channels whose offset is
+                // more than 2^16 times their scale take the slow path as well
+                const float ic0 = (fabsf(k[0]) >= 1e-30f && fabsf(k[1]) <= 65536.f * fabsf(k[0])) ? 1.f / k[0] : 0.f;
                 f32x2 kz = {ic0, fmaf(k[1], ic0, k[3])};
                 CZ[base + ci] = kz;
             }
