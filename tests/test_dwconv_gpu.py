@@ -65,7 +65,7 @@ def test_dwconv_forward_backward_vs_fp64(K, S, Lin):
 
 
 @pytest.mark.parametrize("K,S,Lin", [(3, 1, 13), (5, 2, 21), (3, 2, 16), (5, 2, 128), (3, 1, 64), (3, 2, 33), (3, 1, 2), (5, 2, 3)])
-def test_dwconv_backward_with_recomputed_z(K, S, Lin):
+def test_dwconv_backward_with_recomputed_z(K, S, Lin, monkeypatch):
     """trunet_dwconv_bwd_rz (round 3): the backward that recomputes the conv's raw output z from its input rows instead of
     reading it.  With z = the forward kernel's own output both entry points must agree BIT FOR BIT on the data gradient and the
     weight / bias gradient sums (same dz, same order), chunk boundaries and ragged lengths included; the z-reading one is
@@ -73,6 +73,7 @@ def test_dwconv_backward_with_recomputed_z(K, S, Lin):
     from tinyrecurrentunet_amd import _lib as L
     from tinyrecurrentunet_amd._lib import check, ptr
     lib, st = L.lib(), L.stream()
+    monkeypatch.setenv("TRUNET_DW_RZ", "2")      # also for fewer than 32 output positions (the entry point refuses those: slower)
     g = torch.Generator(device=DEV)
     g.manual_seed(7 + 100 * K + 10 * S + Lin)
     rnd = lambda *s: torch.randn(*s, generator=g, device=DEV)
@@ -119,4 +120,8 @@ def test_dwconv_backward_rz_refuses_other_shapes():
     t = torch.zeros(4 * 9 * 128, device=DEV)
     rc = lib.trunet_dwconv_bwd_rz(ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), ptr(t),
                                   ptr(t), ptr(t), 4, 5, 1, 9, 9, 128, 100, st)
+    assert rc == L.TRUNET_ENOTSUP
+    # a supported (k, stride) with fewer than 32 output positions: refused as well (the z-reading kernel is faster there)
+    rc = lib.trunet_dwconv_bwd_rz(ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), ptr(t),
+                                  ptr(t), ptr(t), 4, 3, 2, 9, 5, 128, 100, st)
     assert rc == L.TRUNET_ENOTSUP

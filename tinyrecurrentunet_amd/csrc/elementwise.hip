@@ -1006,6 +1006,9 @@ extern "C" int trunet_dwconv_bwd_rz(const float* dy, const float* bias, const fl
     if (off || dw_gather_forced() || Lout != (Lin + 2 * (K / 2) - K) / S + 1 ||
         !((K == 3 && S == 1) || (K == 5 && S == 2) || (K == 3 && S == 2)))
         return TRUNET_ENOTSUP;
+    // few output positions: the two warm-up groups per chunk and the four-row window cost more than the z row they save
+    // (encoder.5, k3 s2, 32 -> 16 positions: 331 us against 308 us for the z-reading kernel)
+    if (Lout < 32 && !(getenv("TRUNET_DW_RZ") && getenv("TRUNET_DW_RZ")[0] == '2')) return TRUNET_ENOTSUP;
     const dim3 g2(DW2_FB, C, DW2_CH);
 #define DW2_BWD(KK, SS) hipLaunchKernelGGL((dw2_bwd_rz_kernel<KK, SS>), g2, dim3(256), 0, ST, dy, bias, ca, cb, cc, zin, s_in,  \
                                            t_in, mean_in, w, dy_in, partials_in, w_partials, b_partials, C, Lin, Lout, NP, N)
