@@ -127,7 +127,7 @@ struct DRun {
     int lrow;             // this lane's first row (channel 32*ct + 4h) of the source as staged in an LDS slot
 };
 
-// AK: k-pairs of the data-gradient A fragments = padded dz rows / 2 (32 for M <= 64, 64 for M <= 128)
+// AK: k-pairs of the data-gradient A fragments = padded dz rows / 2 (16 for M <= 32, 32 for M <= 64, 64 for M <= 128)
 // SEC: data-gradient waves carry a second row tile (six row tiles over four waves); it never has statistics
 // KSPLIT (layers with TWO source row tiles, e.g. encoder.1's 64 -> 128): the four data-gradient waves work on EVERY tile,
 // wave j on row tile j & 1 and the K half j >> 1 of the dz rows; the two halves of a row tile meet through LDS (each wave
@@ -803,8 +803,10 @@ extern "C" int trunet_pw_bwd(const trunet_pwbwd_args* H, void* stream) {
     if (h->NP <= 0 || (h->NP % TRUNET_TILE_FRAMES) != 0 || h->N > h->NP || h->P <= 0 || h->M <= 0) return TRUNET_EINVAL;
     if (h->a_mode != TRUNET_PRO_BNBWD || !h->ac0 || !h->ac1 || !h->ac2) return TRUNET_ENOTSUP;
     hipStream_t st = (hipStream_t)stream;
-    if (h->M <= 8) {
-        // thin layer (decoder.5's Conv1d(128 -> 8)): vector-ALU kernel, same contract
+    static const bool thin_valu = [] { const char* e = getenv("TRUNET_PWB_THIN_VALU"); return e && e[0] == '1'; }();
+    if (h->M <= 8 && thin_valu) {
+        // thin layer (decoder.5's Conv1d(128 -> 8)) on the vector-ALU kernel, same contract: slower than three separate
+        // launches (A/B, round 2); the default since round 3 is the MFMA kernel below on a 32-row padded dz block
         for (int s = 0; s < h->nseg; ++s) {
             const trunet_seg& sg = h->seg[s];
             const trunet_dgrad_out& dg = H->dg[s];
@@ -819,8 +821,11 @@ extern "C" int trunet_pw_bwd(const trunet_pwbwd_args* H, void* stream) {
         }
         return trunet_launch_pw_bwd_small(H, st);
     }
-    if (h->M > 128 || (h->M % 32) != 0) return TRUNET_ENOTSUP;
-    const int MA = h->M <= 64 ? 64 : 128;
+    // M <= 32 (decoder.5: 8 rows): one padded 32-row dz tile.  7/8 of its MFMAs multiply zeros, but the layer moves 34 KB per
+    // tile for 32 MFMA times per SIMD -- it is bound by its bytes either way -- and one pass over (dy, z, sources) replaces
+    // conv_wgrad + two conv_gemm launches that read the 128 source rows twice
+    if (h->M > 128 || (h->M > 32 && (h->M % 32) != 0)) return TRUNET_ENOTSUP;
+    const int MA = h->M <= 32 ? 32 : (h->M <= 64 ? 64 : 128);
     int ktiles = 0, ntot = 0;
     for (int s = 0; s < h->nseg; ++s) {
         const trunet_seg& sg = h->seg[s];
@@ -841,6 +846,7 @@ extern "C" int trunet_pw_bwd(const trunet_pwbwd_args* H, void* stream) {
         ntot += sg.nchan;
     }
     if (ktiles * (MA / 32) > 4 * PMAXT || ntot > 4 * 8 * PSW) return TRUNET_ENOTSUP;
+    if (MA == 32 && ktiles != 4) return TRUNET_ENOTSUP;
     PwbSched sch;
     for (int j = 0; j < 4; ++j) {
         sch.rt[j] = -1; sch.period[j] = 1; sch.phase[j] = 0; sch.share[j] = 0;
@@ -893,7 +899,8 @@ extern "C" int trunet_pw_bwd(const trunet_pwbwd_args* H, void* stream) {
             return TRUNET_ELAUNCH;                                                                                     \
         hipLaunchKernelGGL(kern, dim3(PWB_GRID), dim3(512), lds, st, *H, sch, NB, rows);                               \
     } while (0)
-    if (MA == 64 && sec) PWB_LAUNCH(32, true, false);
+    if (MA == 32) PWB_LAUNCH(16, false, false);
+    else if (MA == 64 && sec) PWB_LAUNCH(32, true, false);
     else if (MA == 64 && ksplit) PWB_LAUNCH(32, false, true);
     else if (MA == 64) PWB_LAUNCH(32, false, false);
     else if (ksplit) PWB_LAUNCH(64, false, true);

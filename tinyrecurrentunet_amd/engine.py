@@ -32,7 +32,7 @@ FUSED_PWBWD = os.environ.get("TRUNET_FUSED_PWBWD", "1") != "0"
 # engine's own forward (tests that hand it the bf16 engine's rounded state).
 DW_RZ = os.environ.get("TRUNET_DW_RZ", "1") != "0"
 
-FUSED_THIN = os.environ.get("TRUNET_FUSED_THIN", "0") == "1"
+FUSED_THIN = os.environ.get("TRUNET_FUSED_THIN", "1") != "0"
 
 # Backward of the 64 -> 64 transposed convs (decoder.0 .. decoder.4): one fused launch (trunet_convt_bwd) instead of
 # trunet_conv_wgrad + trunet_conv_gemm over the tap segments; TRUNET_FUSED_CONVT=0 keeps the separate launches.
@@ -841,9 +841,8 @@ class TRUNetEngine:
                 fl_ = 4.0 * N * M * sum(s.nchan * _seg_positions(s, 0, P) for s in segs)
                 # the instance trunet_pw_bwd launches, as rocprofv3 prints it: <AK, SEC, KSPLIT> (KSPLIT: two source row tiles)
                 ksplit = K == 64 and os.environ.get("TRUNET_PWB_KSPLIT", "1") != "0"
-                name = "pw_bwd_small_kernel" if M <= 8 else \
-                    "pw_bwd_kernel<%d, %s, %s>" % (32 if M <= 64 else 64, "true" if K == 192 else "false",
-                                                   "true" if ksplit else "false")
+                name = "pw_bwd_kernel<%d, %s, %s>" % (16 if M <= 32 else (32 if M <= 64 else 64), "true" if K == 192 else "false",
+                                                      "true" if ksplit else "false")
                 with _Timed(name, fl_, "M%d K%s P%d" % (M, "+".join(str(s.nchan) for s in segs), P)):
                     rc = lib.trunet_pw_bwd(a, L.stream())
             else:
@@ -911,10 +910,9 @@ class TRUNetEngine:
             if q1 < x1.L:
                 dy_x1[:, q1:].zero_()
         outs = [dict(out=dy_x1, src=x1_mask)] + ([dict(out=g_skip)] if skip is not None else [])
-        # decoder.5's 8-row layer stays on the three separate launches (1.56 ms): trunet_pw_bwd's vector-ALU variant for
-        # <= 8 rows is correct but slower at this size (2.5 ms with 4 blocks per partial image, 3.6 ms with one; same-box
-        # A/B); TRUNET_FUSED_THIN=1 selects it
-        fused = FUSED_PWBWD and (pw.out_channels % 32 == 0 or (pw.out_channels <= 8 and FUSED_THIN))
+        # decoder.5's 8-row layer: trunet_pw_bwd pads its dz block to one 32-row MFMA tile (round 3; TRUNET_FUSED_THIN=0
+        # keeps the three separate launches of rounds 1-2: conv_wgrad + two conv_gemm, 1.36 ms)
+        fused = FUSED_PWBWD and (pw.out_channels % 32 == 0 or (pw.out_channels <= 32 and FUSED_THIN))
         self._pw_bwd(w, N=N, NP=NP, P=Lp, M=pw.out_channels, dz=dy_pw, dz1=a_pw.t, dz_bn=a_pw.bn, W=pw.weight,
                      bias=pw.bias, segs=srcs, outs=outs, grads=grads, fused=fused)
 
