@@ -33,6 +33,7 @@ FUSED_PWBWD = os.environ.get("TRUNET_FUSED_PWBWD", "1") != "0"
 DW_RZ = os.environ.get("TRUNET_DW_RZ", "1") != "0"
 
 FUSED_THIN = os.environ.get("TRUNET_FUSED_THIN", "1") != "0"
+FUSED_GRU_PROJ = os.environ.get("TRUNET_FUSED_GRU_PROJ", "1") != "0"
 
 # Backward of the 64 -> 64 transposed convs (decoder.0 .. decoder.4): one fused launch (trunet_convt_bwd) instead of
 # trunet_conv_wgrad + trunet_conv_gemm over the tap segments; TRUNET_FUSED_CONVT=0 keeps the separate launches.
@@ -796,7 +797,8 @@ class TRUNetEngine:
             return make_seg(dy_, C, Ln, mode=PRO_NONE, **kw)
         return make_seg(dy_, C, Ln, mode=PRO_BNBWD, src1=z_, c0=bn_.ca, c1=bn_.cb, c2=bn_.cc, **kw)
 
-    def _pw_bwd(self, w, *, N, NP, P, M, dz, dz1, dz_bn, W, bias, segs, outs, grads, fused=True):
+    def _pw_bwd(self, w, *, N, NP, P, M, dz, dz1, dz_bn, W, bias, segs, outs, grads, fused=True, a_m_off=0, w_m_off=0,
+                b_off=0, must_fuse=False):
         """Backward of a Conv1d(k=1)+BatchNorm layer: weight/bias gradient and, per source segment, the data gradient with
         its ReLU mask / skip accumulation / BatchNorm-backward statistics.
         outs[i] = dict(out=tensor, src=Act or None (mask, + statistics when src.bn), accum=bool).
@@ -808,15 +810,17 @@ class TRUNetEngine:
             a = PwBwdArgs()
             aw = a.w
             aw.NP, aw.N, aw.P, aw.p_begin = NP, N, P, 0
-            aw.M, aw.a_L, aw.a_pos_off, aw.a_m_off = M, P, 0, 0
-            aw.ldw_m, aw.ldw_c, aw.w_m_off = K, 1, 0
+            # a_m_off / w_m_off / b_off: a ROW BLOCK of a wider layer (the GRU input projection, 2 x 192 rows, as blocks of
+            # 128 + 64): first dz row, first weight row inside W, first bias row
+            aw.M, aw.a_L, aw.a_pos_off, aw.a_m_off = M, P, 0, a_m_off
+            aw.ldw_m, aw.ldw_c, aw.w_m_off = K, 1, w_m_off
             aw.nseg = len(segs)
             aw.a0, aw.a1 = ptr(dz), ptr(dz1)
             aw.a_mode = PRO_BNBWD
             aw.ac0, aw.ac1, aw.ac2 = ptr(dz_bn.ca), ptr(dz_bn.cb), ptr(dz_bn.cc)
             aw.w_numel = self._wg_total                     # image stride of the shared buffer
             aw.w_partials, aw.b_partials = self._wg_slot(W), self._wg_slot(bias)
-            aw.b_stride, aw.b_off = self._wg_total, 0
+            aw.b_stride, aw.b_off = self._wg_total, b_off
             a.W = ptr(W.data)
             nparts = lib.trunet_pw_bwd_nparts()
             stat_parts = []
@@ -851,8 +855,9 @@ class TRUNetEngine:
                 for bn, pname in stat_parts:
                     self._bn_bwd(w, bn, nparts, grads, part_name=pname)
                 return
-            if rc != L.TRUNET_ENOTSUP:
+            if rc != L.TRUNET_ENOTSUP or must_fuse:
                 check(rc, "pw_bwd")
+        assert not (a_m_off or w_m_off or b_off), "row blocks exist on the fused kernel only"
         # ---- separate launches
         self._wgrad(w, N=N, NP=NP, P=P, M=M, dz=dz, dz1=dz1, dz_L=P, dz_bn=dz_bn, W=W, ldw_m=K, ldw_c=1, segs=segs,
                     grads=grads, bias=bias)
@@ -948,6 +953,17 @@ class TRUNetEngine:
         self._bn_bwd(w, a_pw.bn, nparts, grads, part_name="ct_partials")
         return True
 
+    def _ident_bnbwd(self, w, C):
+        """(ca, cb, cc) = (1, 0, 0): a dz operand that is already the gradient of the raw output, for kernels whose dz
+        prologue is the BatchNorm backward ca dy + cb z + cc"""
+        t = w.t.get("ident_bnbwd%d" % C)
+        if t is None:
+            import types
+            ca = torch.ones(C, device=self._wg_base.device, dtype=torch.float32)
+            zz = torch.zeros(C, device=self._wg_base.device, dtype=torch.float32)
+            t = w.t["ident_bnbwd%d" % C] = types.SimpleNamespace(ca=ca, cb=zz, cc=zz.clone())
+        return t
+
     def _bwd_fgru(self, w, N, NP, blk, up, hout, src, src_mask, dy_src, grads):
         """GRUBlock(128, 64, 64, True) (network.py:45-58): pointwise conv over hout, the recurrence, the input
         projection; dy_src receives the gradient of the block input ``src`` (masked + statistics when src_mask)."""
@@ -964,6 +980,9 @@ class TRUNetEngine:
         gates = w.t["gates"]
         check(lib.trunet_gru_bwd(ptr(dhout), ptr(hout.t), ptr(gates), ptr(gru.weight_hh_l0.data),
                                  ptr(gru.weight_hh_l0_reverse.data), ptr(dgi), ptr(dghn), Hh, Lg, NP, N, st), "gru_bwd")
+        # (TRUNET_FUSED_GRU_PROJ=0: conv_wgrad + conv_gemm for the projection, rounds 1-2)
+        fuse_proj = (FUSED_PWBWD and FUSED_GRU_PROJ and src_mask is not None and src_mask.bn is not None and
+                     src_mask.t is src.t and 3 * Hh > 128 and (3 * Hh - 128) % 32 == 0 and gru.input_size % 32 == 0)
         for d, sfx in enumerate(("", "_reverse")):
             whh = getattr(gru, "weight_hh_l0" + sfx)
             bhh = getattr(gru, "bias_hh_l0" + sfx)
@@ -975,9 +994,29 @@ class TRUNetEngine:
                         ldw_m=Hh, ldw_c=1, segs=[hseg], grads=grads, bias=bhh, b_off=0)
             self._wgrad(w, N=N, NP=NP, P=Lg, M=Hh, dz=dghn, dz_L=Lg, dz_bn=None, a_m_off=d * Hh, w_m_off=2 * Hh,
                         W=whh, ldw_m=Hh, ldw_c=1, segs=[hseg], grads=grads, bias=bhh, b_off=2 * Hh)
+            if fuse_proj:
+                continue
             # input projection weights: all 3H = 192 rows of dgi for this direction in one launch
             self._wgrad(w, N=N, NP=NP, P=Lg, M=3 * Hh, dz=dgi, dz_L=Lg, dz_bn=None, a_m_off=d * 3 * Hh, W=wih_p,
                         ldw_m=gru.input_size, ldw_c=1, segs=[src.seg()], grads=grads, bias=bih_p, b_off=0)
+        if fuse_proj:
+            # The input projection IS a pointwise layer (gi = W_ih a(src) + b_ih, 2 x 192 rows): its backward on the fused
+            # kernel, one launch per row block (128 + 64 rows per direction; dz = dgi through the identity "BatchNorm
+            # backward" ca = 1, cb = cc = 0).  Each launch writes its block of dW_ih / db_ih and ADDS its share of
+            # W_ih^T dgi into dy_src under the source's ReLU mask (idempotent, so applying it at every launch is exact);
+            # the BatchNorm-backward sums are taken by the last launch, from the finished gradient.  Replaces two
+            # conv_wgrad launches and a conv_gemm that read the 384 dgi rows twice (K = 384 does not fit its LDS weight
+            # block next to 128 output rows): 1.48 -> 1.25 ms.
+            ident = self._ident_bnbwd(w, 6 * Hh)
+            blocks = [(d, r0, m) for d in (0, 1) for (r0, m) in ((0, 128), (128, 3 * Hh - 128))]
+            for i, (d, r0, m) in enumerate(blocks):
+                sfx = "_reverse" if d else ""
+                last = i == len(blocks) - 1
+                o = dict(out=dy_src, src=(src_mask if last else Act(src_mask.t, src_mask.C, src_mask.L)), accum=i > 0)
+                self._pw_bwd(w, N=N, NP=NP, P=Lg, M=m, dz=dgi, dz1=dgi, dz_bn=ident, W=getattr(gru, "weight_ih_l0" + sfx),
+                             bias=getattr(gru, "bias_ih_l0" + sfx), segs=[src.seg()], outs=[o], grads=grads, fused=True,
+                             a_m_off=d * 3 * Hh + r0, w_m_off=r0, b_off=r0, must_fuse=True)
+            return
         # data gradient of the projection -> gradient of the block input (dy of enc5's BN in the full network)
         wih = w.t["wih"]
         kw = {}
