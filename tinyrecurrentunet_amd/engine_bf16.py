@@ -37,6 +37,10 @@ FUSED_CONVT16 = os.environ.get("TRUNET_BF16_FUSED_CONVT", "1") != "0"
 GRU_PROJ16 = os.environ.get("TRUNET_BF16_GRU_PROJ", "1") != "0"
 # the recurrence kernels read and write bf16 octets (trunet_bf16_gru_fwd / _bwd); "0": the fp32 kernels between conversions
 GRU_IO16 = GRU_PROJ16 and os.environ.get("TRUNET_BF16_GRU_IO", "1") != "0"
+# decoder.5's ConvTranspose1d(8 -> 8) on the fp32 thin-layer kernels (conv_smallm / wgrad_last): one octet per frame keeps the
+# bf16 MFMA kernels at 0.4-1 TB/s there (forward 0.24 ms, weight gradient 0.46 ms, data gradient 0.22 ms against 0.14 / 0.16 /
+# 0.14 ms in fp32 for twice the bytes), and the layer's output IS the fp32 module output.  "0": the bf16 kernels
+LAST_CT32 = os.environ.get("TRUNET_BF16_LAST_CT32", "1") != "0"
 # Every packed weight image of a step in one launch at the start of the forward (the plan is learnt during the first
 # step); TRUNET_BF16_BATCH_PACK=0 packs in front of each GEMM instead.
 BATCH_PACK16 = os.environ.get("TRUNET_BF16_BATCH_PACK", "1") != "0"
@@ -468,9 +472,17 @@ class TRUNetEngineBF16(TRUNetEngine):
             left = (skip.L - cur.L) // 2
             cur = acts["dec%d.pw" % i] = self._pw(w, "dec%d.pw" % i, [cur, skip], seq[0], seq[1], N, NP, training,
                                                   x1_left=left)
+            if i == 5 and LAST_CT32:
+                # the stored (rounded) pointwise output as fp32, same BatchNorm state: the transposed conv and its output in fp32
+                pw32 = acts["dec5.pw32"] = Act(self._to32(w, "z:dec5.pw32", cur.t, cur.C, cur.L, NP), cur.C, cur.L, cur.bn)
+                cur = acts["dec5"] = TRUNetEngine._convT(self, w, "dec5.f32", pw32, seq[3], None, N, NP, training)
+                break
             cur = acts["dec%d" % i] = self._convT(w, "dec%d" % i, cur, seq[3], seq[4] if i < 5 else None, N, NP, training)
         out = torch.empty((N, cur.C, cur.L), device=x.device, dtype=torch.float32)
-        check(lib.trunet_bf16_to_ncl(ptr16(cur.t), ptr(out), N, cur.C, cur.L, NP, st), "bf16_to_ncl")
+        if isinstance(cur, Act16):
+            check(lib.trunet_bf16_to_ncl(ptr16(cur.t), ptr(out), N, cur.C, cur.L, NP, st), "bf16_to_ncl")
+        else:
+            check(lib.trunet_from_frames_last(ptr(cur.t), ptr(out), N, cur.C, cur.L, NP, st), "from_frames_last")
         return out, (acts, N, NP, w, w.gen)
 
     # ------------------------------------------------------------------ backward pieces
@@ -612,13 +624,26 @@ class TRUNetEngineBF16(TRUNetEngine):
         self._bn_bwd(w, a_pw.bn, nparts, grads, part_name="ct16_partials")
         return True
 
-    def _bwd_tr16(self, w, N, NP, ct, pw, a_pw, Lo, up, x1, x1_mask, skip, left, dy_x1, g_skip, dy_pw_name, grads):
+    def _bwd_tr16(self, w, N, NP, ct, pw, a_pw, Lo, up, x1, x1_mask, skip, left, dy_x1, g_skip, dy_pw_name, grads, pw32=None):
         """FirstTrCNN / TrCNN / LastTrCNN (network.py:60-120): transposed conv, then the pointwise conv over [x1 | skip]"""
         dy, z, bn = up
         k, s_, pad = ct.kernel_size[0], ct.stride[0], ct.padding[0]
         Ci, Co = ct.in_channels, ct.out_channels
         dy_pw = self._get16(w, dy_pw_name, Ci, a_pw.L, NP)
-        if not (FUSED_CONVT16 and bn is not None and self._convt_bwd16(w, N, NP, ct, a_pw, Lo, dy, z, bn, dy_pw, grads)):
+        if pw32 is not None:
+            # fp32 transposed conv (LAST_CT32): dy is the fp32 output cotangent [Co][Lo][NP]; weight / bias gradient and the
+            # masked data gradient with its BatchNorm-backward sums on the fp32 kernels, the result rounded once to octets
+            self._wgrad(w, N=N, NP=NP, P=Lo, M=Co, dz=dy, dz1=None, dz_L=Lo, dz_bn=None, W=ct.weight, ldw_m=k, ldw_c=Co * k,
+                        segs=[pw32.seg(pos_off=pad - kk, woff=kk, pos_div=s_) for kk in range(k)], grads=grads, bias=ct.bias)
+            dy_pw32 = w.get(dy_pw_name + ".f32", (Ci, a_pw.L, NP))
+            segs = [TRUNetEngine._dz_seg(dy, None, None, Co, Lo, pos_mul=s_, pos_off=kk - pad, woff=kk) for kk in range(k)]
+            nparts = self._gemm(w, N=N, NP=NP, P=a_pw.L, M=Ci, out=dy_pw32, out_L=a_pw.L, W=ct.weight.data, ldw_m=Co * k,
+                                ldw_c=k, segs=segs, zmask=pw32.t, e0=a_pw.bn.scale, e1=a_pw.bn.shift, e2=a_pw.bn.mean,
+                                stats=Ci)
+            self._bn_bwd(w, a_pw.bn, nparts, grads)
+            check(L.lib().trunet_bf16_from_frames_last(ptr(dy_pw32), ptr16(dy_pw), Ci, a_pw.L, NP, L.stream()),
+                  "bf16_from_frames_last")
+        elif not (FUSED_CONVT16 and bn is not None and self._convt_bwd16(w, N, NP, ct, a_pw, Lo, dy, z, bn, dy_pw, grads)):
             self._wgrad16(w, N=N, NP=NP, P=Lo, M=Co, dz=dy, dz1=z, dz_L=Lo, dz_bn=bn, W=ct.weight, ldw_m=k, ldw_c=Co * k,
                           segs=[a_pw.seg(pos_off=pad - kk, woff=kk, pos_div=s_) for kk in range(k)], grads=grads,
                           bias=ct.bias)
@@ -677,8 +702,12 @@ class TRUNetEngineBF16(TRUNetEngine):
         self._wg_begin(w)
         gout = gout.contiguous()
         last = acts["dec5"]
-        dyt = self._get16(w, "dy:dec5", last.C, last.L, NP)
-        check(lib.trunet_bf16_from_ncl(ptr(gout), ptr16(dyt), N, last.C, last.L, NP, st), "bf16_from_ncl")
+        if isinstance(last, Act16):
+            dyt = self._get16(w, "dy:dec5", last.C, last.L, NP)
+            check(lib.trunet_bf16_from_ncl(ptr(gout), ptr16(dyt), N, last.C, last.L, NP, st), "bf16_from_ncl")
+        else:       # LAST_CT32: the last transposed conv ran in fp32, its cotangent stays fp32 frames-last
+            dyt = w.get("dy:dec5.f32", (last.C, last.L, NP))
+            check(lib.trunet_to_frames_last(ptr(gout), ptr(dyt), N, last.C, last.L, NP, st), "to_frames_last")
         up = (dyt, last.t, None)
         for i in range(5, -1, -1):
             seq = (net.decoder[i].LastTrCNN if i == 5 else net.decoder[i].TrCNN) if i > 0 else net.decoder[0].FirstTrCNN
@@ -692,7 +721,7 @@ class TRUNetEngineBF16(TRUNetEngine):
                 x1, skip, left, g_skip = acts[x1n], None, 0, None
             dy_x1 = self._get16(w, "dy:" + x1n, x1.C, x1.L, NP)
             self._bwd_tr16(w, N, NP, seq[3], seq[0], acts["dec%d.pw" % i], acts["dec%d" % i].L, up, x1, x1, skip, left,
-                           dy_x1, g_skip, "dy:dec%d.pw" % i, grads)
+                           dy_x1, g_skip, "dy:dec%d.pw" % i, grads, pw32=(acts.get("dec5.pw32") if i == 5 else None))
             up = (dy_x1, x1.t, x1.bn)
 
         # -------- FGRU (fp32)
