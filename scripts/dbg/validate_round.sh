@@ -20,5 +20,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $P/stream -o s -- python
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/stream_tgru -o s -- python3 $GRAFT_REPO_ROOT/bench.py --streaming --tgru --steps 300 --no-cpu-baseline > $P/stream_tgru.log 2>&1 && echo stream tgru done
 find $GRAFT_REPO_ROOT/gpurun_out -name "*kernel_trace.csv" -size +20M -delete
 cd $GRAFT_REPO_ROOT
-TRUNET_BENCH_LAUNCH_LOG=$GRAFT_REPO_ROOT/gpurun_out/${TAG}_launch_f32.log python bench.py > gpurun_out/${TAG}_bench.txt 2>gpurun_out/${TAG}_bench.err; tail -c 600 gpurun_out/${TAG}_bench.txt
+python bench.py > gpurun_out/${TAG}_bench.txt 2>gpurun_out/${TAG}_bench.err; tail -c 600 gpurun_out/${TAG}_bench.txt
+# per-launch times and flops of the fp32 step (profiles/*_roofline.md): its own run, the extras of the default line would overwrite the log
+TRUNET_BENCH_LAUNCH_LOG=$GRAFT_REPO_ROOT/gpurun_out/${TAG}_launch_f32.log python bench.py --no-cpu-baseline --no-extras > /dev/null 2>&1
 python bench.py --dtype bf16 --no-cpu-baseline > gpurun_out/${TAG}_bench_bf16.txt 2>/dev/null; tail -c 400 gpurun_out/${TAG}_bench_bf16.txt
