@@ -560,6 +560,48 @@ def test_bf16_backward_matches_fp32_backward_on_the_same_forward_state():
     print("worst relative L2 over the parameter gradients: %.3e" % worst)
 
 
+def test_bf16_weight_images_follow_in_place_weight_updates():
+    """The bf16 engine packs every weight into MFMA A-fragment images, all of them in ONE launch at the start of a forward (from the
+    second step on).  An image must be built from the weights of THIS step -- also for the GRU input projection, whose source is a
+    workspace tensor (both directions' W_ih concatenated): until round 3 that concatenation happened AFTER the batched pack, so
+    from the second step on the projection (forward GEMM and the W^T image of its data gradient) ran on the weights of the
+    step before.  Here: forward / backward once (the plan fills), overwrite weights in place as an optimizer does, run again,
+    and compare output and gradients bit for bit with a fresh network that holds the same weights."""
+    from tinyrecurrentunet_amd.network import TRUNet
+    from tinyrecurrentunet_amd import _lib
+    torch.manual_seed(21)
+    a = TRUNet(input_size=4, precision="bf16").cuda().train()
+    g = torch.Generator(device=DEV)
+    g.manual_seed(8)
+    N = 140
+    x = torch.randn(N, 4, 257, generator=g, device=DEV)
+    gout = torch.randn(N, 8, 257, generator=g, device=DEV) / N
+    for _ in range(2):          # two steps: the second one already runs on the batched pack
+        for p in a.parameters():
+            p.grad = None
+        a(x).backward(gout)
+    with torch.no_grad():
+        for n, p in a.named_parameters():
+            if p.dim() > 1 and not n.startswith("TGRU"):
+                p.mul_(0.5).add_(0.01 * torch.randn(p.shape, generator=g, device=DEV))      # in place: same storage
+    _lib.bump_mutation_epoch()
+    for p in a.parameters():
+        p.grad = None
+    ya = a(x)
+    ya.backward(gout)
+    b = TRUNet(input_size=4, precision="bf16").cuda().train()
+    b.load_state_dict(a.state_dict())
+    # BatchNorm running statistics were loaded AFTER a's third forward updated them; they do not enter a training forward
+    yb = b(x)
+    yb.backward(gout)
+    assert torch.equal(ya, yb)
+    pb = dict(b.named_parameters())
+    for n, p in a.named_parameters():
+        if n.startswith("TGRU"):
+            continue
+        assert torch.equal(p.grad, pb[n].grad), n
+
+
 @pytest.mark.parametrize("cin,N", [(4, 501), (3, 130)])
 def test_bf16_network_forward_and_gradients_vs_fp32(cin, N):
     """SURVEY 8d gate for configs[2].  The survey proposed "forward <= 1e-2 relative"; measured, the randomly initialised

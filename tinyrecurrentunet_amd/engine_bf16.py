@@ -318,10 +318,7 @@ class TRUNetEngineBF16(TRUNetEngine):
         rows that write fp32 frames-last gi for the fp32 recurrence kernel"""
         lib = L.lib()
         Hh = gru.hidden_size
-        wih = w.get("wih", (6 * Hh, gru.input_size))
-        bih = w.get("bih", (6 * Hh,))
-        torch.cat((gru.weight_ih_l0.data, gru.weight_ih_l0_reverse.data), 0, out=wih)
-        torch.cat((gru.bias_ih_l0.data, gru.bias_ih_l0_reverse.data), 0, out=bih)
+        wih, bih = w.t["wih"], w.t["bih"]       # concatenated by forward() BEFORE the batched weight pack read them
         Lg = cur.L
         if GRU_IO16:
             # gi, the recurrence output and the saved gates as octets: no fp32 tensor and no conversion launch on this path
@@ -427,6 +424,14 @@ class TRUNetEngineBF16(TRUNetEngine):
             w.gen += 1
         lib, st = L.lib(), L.stream()
         acts = {}
+        if GRU_PROJ16:
+            # both directions' W_ih / b_ih as one 384-row operand.  This workspace tensor is a SOURCE of the batched weight pack
+            # below, so it must hold this step's weights before that launch reads it (until round 3 the concatenation sat in
+            # _gru16, after the pack: from the second step on the projection ran on the weights of the step before)
+            gru = net.FGRU.GRU
+            Hh = gru.hidden_size
+            torch.cat((gru.weight_ih_l0.data, gru.weight_ih_l0_reverse.data), 0, out=w.get("wih", (6 * Hh, gru.input_size)))
+            torch.cat((gru.bias_ih_l0.data, gru.bias_ih_l0_reverse.data), 0, out=w.get("bih", (6 * Hh,)))
         self._pack_all()
 
         x16t = self._get16(w, "x16", Cin, F_BINS, NP)
