@@ -560,7 +560,8 @@ def test_bf16_backward_matches_fp32_backward_on_the_same_forward_state():
     print("worst relative L2 over the parameter gradients: %.3e" % worst)
 
 
-def test_bf16_weight_images_follow_in_place_weight_updates():
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_bf16_weight_images_follow_in_place_weight_updates(precision):
     """The bf16 engine packs every weight into MFMA A-fragment images, all of them in ONE launch at the start of a forward (from the
     second step on).  An image must be built from the weights of THIS step -- also for the GRU input projection, whose source is a
     workspace tensor (both directions' W_ih concatenated): until round 3 that concatenation happened AFTER the batched pack, so
@@ -570,7 +571,7 @@ def test_bf16_weight_images_follow_in_place_weight_updates():
     from tinyrecurrentunet_amd.network import TRUNet
     from tinyrecurrentunet_amd import _lib
     torch.manual_seed(21)
-    a = TRUNet(input_size=4, precision="bf16").cuda().train()
+    a = TRUNet(input_size=4, precision=precision).cuda().train()      # (fp32: no packed images; the same contract)
     g = torch.Generator(device=DEV)
     g.manual_seed(8)
     N = 140
@@ -589,7 +590,7 @@ def test_bf16_weight_images_follow_in_place_weight_updates():
         p.grad = None
     ya = a(x)
     ya.backward(gout)
-    b = TRUNet(input_size=4, precision="bf16").cuda().train()
+    b = TRUNet(input_size=4, precision=precision).cuda().train()
     b.load_state_dict(a.state_dict())
     # BatchNorm running statistics were loaded AFTER a's third forward updated them; they do not enter a training forward
     yb = b(x)
