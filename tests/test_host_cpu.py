@@ -396,6 +396,17 @@ def test_bf16_entry_points_reject_null_and_bad_shapes():
     assert lib.trunet_bf16_dwconv_fwd(0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000, None, 16, 3, 1, 8, 8, 256, 200,
                                       None) == EINVAL                   # no partials buffer
     assert lib.trunet_bf16_from_frames_last(None, 0x1000, 8, 4, 256, None) == EINVAL
+    # round-3 entry points: argument checks come before any launch
+    P = 0x1000
+    assert lib.trunet_bf16_gru_fwd(None, P, P, P, P, P, P, 64, 16, 256, None) == EINVAL
+    assert lib.trunet_bf16_gru_fwd(P, P, P, P, P, P, None, 64, 16, 200, None) == EINVAL        # NP not a multiple of 128
+    assert lib.trunet_bf16_gru_fwd(P, P, P, P, P, P, None, 32, 16, 256, None) == ENOTSUP       # hidden size other than 64
+    assert lib.trunet_bf16_gru_bwd(P, P, None, P, P, P, P, 64, 16, 256, None) == EINVAL         # backward needs the saved gates
+    assert lib.trunet_bf16_gru_bwd(P, P, P, P, P, P, P, 128, 16, 256, None) == ENOTSUP
+    assert lib.trunet_dwconv_bwd_rz(P, None, P, P, P, P, P, P, P, P, P, P, P, P, 8, 3, 1, 64, 64, 256, 200, None) == EINVAL
+    assert lib.trunet_dwconv_bwd_rz(P, P, P, P, P, P, P, P, P, P, P, P, P, P, 8, 3, 1, 64, 64, 200, 200, None) == EINVAL  # NP % 128
+    assert lib.trunet_dwconv_bwd_rz(P, P, P, P, P, P, P, P, P, P, P, P, P, P, 8, 7, 1, 64, 64, 256, 200, None) == ENOTSUP  # k = 7
+    assert lib.trunet_dwconv_bwd_rz(P, P, P, P, P, P, P, P, P, P, P, P, P, P, 8, 3, 2, 32, 16, 256, 200, None) == ENOTSUP  # < 32 outputs
     assert lib.trunet_bf16_dw_nparts(512, 64) == 2 * 4 and lib.trunet_bf16_gemm_nparts() > 0
     # fp32 GEMM family: strides other than 1 / 2 are refused (segment positions are computed with shifts)
     g = _lib.GemmArgs()
