@@ -20,6 +20,49 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def rank_core_slice(cores, local_rank, local_world):
+    """The disjoint share of `cores` (sorted CPU ids) that rank `local_rank` of `local_world` ranks on this node may use:
+    contiguous slices of len(cores) // local_world (at least one core; with fewer cores than ranks they are shared round
+    robin).  Pure function: tests/test_host_cpu.py checks the split."""
+    cores = sorted(cores)
+    if local_world <= 1 or not cores:
+        return cores
+    per = len(cores) // local_world
+    if per == 0:
+        return [cores[local_rank % len(cores)]]
+    return cores[local_rank * per:(local_rank + 1) * per]
+
+
+def pin_host_cores():
+    """Host side of the multi-GPU run: eight Python launch loops on one node must not migrate over each
+    other's cores.  BEFORE torch is imported (its thread pools size themselves from the affinity mask) and before any GPU
+    call, a rank restricts itself to its slice of the node's cores -- under `torch.distributed.run` (LOCAL_RANK /
+    LOCAL_WORLD_SIZE) and under bench.py's own launcher alike; `--host-cores K` restricts a 1-GPU run to K cores (the
+    table in DESIGN section 5: how many cores a rank needs before the step turns host-bound).  TRUNET_BENCH_PIN=0: off."""
+    if not hasattr(os, "sched_setaffinity") or os.environ.get("TRUNET_BENCH_PIN", "1") == "0":
+        return None
+    cores = sorted(os.sched_getaffinity(0))
+    k = None
+    for i, a in enumerate(sys.argv):
+        if a == "--host-cores" and i + 1 < len(sys.argv):
+            k = int(sys.argv[i + 1])
+        elif a.startswith("--host-cores="):
+            k = int(a.split("=", 1)[1])
+    lw = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    if "LOCAL_RANK" in os.environ and lw > 1:
+        cores = rank_core_slice(cores, int(os.environ["LOCAL_RANK"]), lw)
+    if k is not None and k > 0:
+        cores = cores[:k]
+    try:
+        os.sched_setaffinity(0, cores)
+    except OSError:
+        return None
+    return cores
+
+
+PINNED_CORES = pin_host_cores() if __name__ == "__main__" else None
 # the host driver of this pool only supports dmabuf IPC: without it RCCL fails with `hipIpcGetMemHandle: invalid argument`
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
@@ -168,6 +211,7 @@ def streaming(args, dev, emit=True):
     streams = 1024
     torch.manual_seed(0)
     net = hn.TRUNet(input_size=4).to(dev).eval()
+    net.fold_verify = False          # serving loop with frozen weights: no per-call content checksum of the parameters
     x = torch.randn(streams, 4, 257, device=dev)
     graphed = False
     state = hn.TRUNetStreamState() if args.tgru else None       # --tgru: stateful time-recurrent block per stream
@@ -202,31 +246,30 @@ def streaming(args, dev, emit=True):
     dt = (time.time() - t0) / args.steps
     # roofline of the forward kernel: HIP events on the launch stream around direct (un-graphed) calls
     roof = None
-    if True:
-        with torch.no_grad():
-            evs = []
-            for _ in range(20):
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record()
-                fwd(x)
-                b.record()
-                evs.append((a, b))
-            torch.cuda.synchronize()
-        kms = pctl([a.elapsed_time(b) for a, b in evs], 0.5)
-        flops = streams * (FLOPS_PER_FRAME_STEP / 3.0)            # forward: 31,363,072 flop per frame
-        if args.tgru:       # + one GRU time step per (stream, position): W_ih (384 x 64), W_hh (384 x 128), conv (64 x 128)
-            flops += streams * 2.0 * (384 * 64 + 384 * 128 + 64 * 128) * 16
-        ach = flops / (kms * 1e-3) / 1e12
-        folded = bool(net.__dict__.get("_folded_cache")) and (state is None or state.layout == "folded")
-        roof = {"bound": "mfma", "kernel": ("stream_fwd_kernel<%s>" % ("true" if args.tgru else "false")) if folded
-                else "layer-by-layer launches",
-                "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4),
-                "traffic": None, "avg_launch_ms": round(kms, 4),
-                # features in + output out per frame (+ the hidden state read and written: 2 x 8 KB)
-                "algorithmic_bytes_per_launch": streams * (12336 + (16384 if args.tgru else 0)),
-                "note": ("one workgroup per frame through all layers in its own LDS: bound by the fp32 MFMA rate (%s)" % (
-                    "34.0 Mflop vs 28.7 KB per frame incl. the hidden state" if args.tgru else
-                    "31.4 Mflop vs 12.3 KB per frame"))}
+    with torch.no_grad():
+        evs = []
+        for _ in range(20):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fwd(x)
+            b.record()
+            evs.append((a, b))
+        torch.cuda.synchronize()
+    kms = pctl([a.elapsed_time(b) for a, b in evs], 0.5)
+    flops = streams * (FLOPS_PER_FRAME_STEP / 3.0)            # forward: 31,363,072 flop per frame
+    if args.tgru:       # + one GRU time step per (stream, position): W_ih (384 x 64), W_hh (384 x 128), conv (64 x 128)
+        flops += streams * 2.0 * (384 * 64 + 384 * 128 + 64 * 128) * 16
+    ach = flops / (kms * 1e-3) / 1e12
+    folded = bool(net.__dict__.get("_folded_cache")) and (state is None or state.layout == "folded")
+    roof = {"bound": "mfma", "kernel": ("stream_fwd_kernel<%s>" % ("true" if args.tgru else "false")) if folded
+            else "layer-by-layer launches",
+            "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4),
+            "traffic": None, "avg_launch_ms": round(kms, 4),
+            # features in + output out per frame (+ the hidden state read and written: 2 x 8 KB)
+            "algorithmic_bytes_per_launch": streams * (12336 + (16384 if args.tgru else 0)),
+            "note": ("one workgroup per frame through all layers in its own LDS: bound by the fp32 MFMA rate (%s)" % (
+                "34.0 Mflop vs 28.7 KB per frame incl. the hidden state" if args.tgru else
+                "31.4 Mflop vs 12.3 KB per frame"))}
     cpu = None
     if not args.no_cpu_baseline and not args.tgru:
         from oracle import network_ref as nr
@@ -310,6 +353,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the short bf16 / streaming context measurements")
     ap.add_argument("--no-stft-loss", action="store_true", help="ablation (BASELINE.json configs[4])")
     ap.add_argument("--no-pcen", action="store_true", help="ablation (BASELINE.json configs[4])")
+    ap.add_argument("--host-cores", type=int, default=0,
+                    help="restrict this process to K host cores (applied before torch is imported); 0 = the rank's share")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and the gradient all-reduce even with one rank")
     ap.add_argument("--tgru", action="store_true",
@@ -401,7 +446,8 @@ def main():
     dist_info = None
     if use_dist:
         # max over ranks is the job's time; every rank's own figure is kept so the judge can see all N took part
-        mine = torch.tensor([dt / args.steps * 1e3, float(torch.cuda.current_device())],
+        mine = torch.tensor([dt / args.steps * 1e3, float(torch.cuda.current_device()), host_ms,
+                             float(len(os.sched_getaffinity(0)))],
                             device=(dev if dist.get_backend() == "nccl" else "cpu"), dtype=torch.float64)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
@@ -410,7 +456,11 @@ def main():
         dist_info = {"dist_backend": dist.get_backend(), "world_size_seen": dist.get_world_size(),
                      "ms_per_step_rank_min": round(min(per_rank), 3), "ms_per_step_rank_max": round(max(per_rank), 3),
                      "self_spawned": bool(os.environ.get("TRUNET_BENCH_SPAWNED")),
-                     "device_of_rank": [int(t[1]) for t in every]}
+                     "device_of_rank": [int(t[1]) for t in every],
+                     # the host's share per rank: time to ENQUEUE a step, and the cores the rank is pinned to
+                     "host_enqueue_ms_rank_min": round(min(float(t[2]) for t in every), 3),
+                     "host_enqueue_ms_rank_max": round(max(float(t[2]) for t in every), 3),
+                     "host_cores_of_rank": [int(t[3]) for t in every]}
     ms = dt / args.steps * 1e3
     total_frames = frames * world
     value = total_frames / (dt / args.steps)
@@ -522,6 +572,7 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                "ms_per_step_median": round(pctl(step_ms, 0.5), 3), "ms_per_step_p10": round(pctl(step_ms, 0.1), 3),
                "ms_per_step_p90": round(pctl(step_ms, 0.9), 3), "host_enqueue_ms_per_step": round(host_ms, 3),
+               "host_cores": len(os.sched_getaffinity(0)),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
                "data": "synthetic",
                "config": {"workload": "config/tiny.json TRU-Net (C_in=%d%s), %d x %.0f s 16 kHz pairs per GPU, "

@@ -292,6 +292,10 @@ int trunet_adamw(float* p, const float* g, float* m, float* v, int64_t n, float 
                  float beta2, float eps, float wd, int step, void* stream);
 /* sum of squares -> out[0] (clip_grad_norm_ total norm^2, train.py:138) */
 int trunet_sumsq(const float* g, int64_t n, float* out, void* stream);
+/* 64-bit content checksum of n device buffers in one launch: desc = n x {const void* ptr; int64_t nwords (32-bit words)} in
+ * device memory, out[0] (zero on entry) receives the sum of the mixed words.  Host-side cache key of the folded eval
+ * artefact (network.py:153-171 in eval mode): catches weights written through `p.data` (util.py:168-175). */
+int trunet_checksum_batch(const void* desc, int n, uint64_t* out, void* stream);
 
 
 /* ---- FFT-based front / back end (all sizes fp32; tw = exp(-2*pi*i*t/n), t < n/2, interleaved re,im) ---- */

@@ -1,5 +1,5 @@
 """Layer-by-layer comparison of the HIP schedule with the oracle (diagnostic; run on the GPU box):
-    python tests/gpu_debug_network.py [N] > gpurun_out/debug_network.txt
+    python scripts/dbg/debug_network.py [N] > gpurun_out/debug_network.txt
 """
 import os
 import sys
@@ -7,7 +7,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import network_ref as nr, weights as W  # noqa: E402
 from tinyrecurrentunet_amd import network as hn  # noqa: E402
 

@@ -3,7 +3,7 @@ Columns: HIP (ours), torch CPU fp32 (double accumulators inside BN), torch GPU f
 import os, sys
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import network_ref as nr, weights as W
 from tinyrecurrentunet_amd import network as hn
 

@@ -483,6 +483,69 @@ def test_bf16_gru_kernels_match_the_fp32_recurrence_on_the_same_operands():
     close(dghn16, dghn, 2 * Hh, "dghn")
 
 
+def test_bf16_gru_backward_vs_the_exact_fp32_recurrence():
+    """bgru_bwd_kernel takes h_{t-1} from the bf16-rounded recurrence output and r, z, n, gh from bf16 gate planes,
+    while the forward carried h in fp32 -- so what it computes is not exactly the gradient of the forward that ran.  How far
+    off is it?  The fp32 kernels (trunet_gru_fwd / _bwd, exact fp32 hout and gates, pinned by block_gru_bi.npz and the fp64
+    oracle) on the same bf16-representable gi and dhout are the yardstick: relative L2 of dgi, dghn and of the recurrent
+    weight gradients dW_hh = sum_t dg_t h_{t-1}^T formed from either result (what trunet_bf16_wgrad computes from them).
+    Measured (round 4, 1x MI355X, N = 384 x 16 steps): see the printed line; bounds at ~3x.  TRUNET_BF16_GRU_IO=0 keeps
+    the exact fp32 recurrence between conversion launches."""
+    from tinyrecurrentunet_amd import _lib as L
+    from tinyrecurrentunet_amd._lib import check, ptr, ptr16
+    lib, st = L.lib(), L.stream()
+    rnd = _gen(43)
+    Hh, Lg, NP = 64, 16, 384
+    whh = [rnd(3 * Hh, Hh) * 0.15 for _ in range(2)]
+    bhh = [rnd(3 * Hh) * 0.1 for _ in range(2)]
+    gi = _rb(rnd(6 * Hh, Lg, NP))
+    dhout = _rb(rnd(2 * Hh, Lg, NP))
+    # exact fp32 forward + backward
+    hout = torch.empty(2 * Hh, Lg, NP, device=DEV)
+    gates = torch.empty(2, 4, Hh, Lg, NP, device=DEV)
+    check(lib.trunet_gru_fwd(ptr(gi), ptr(whh[0]), ptr(bhh[0]), ptr(whh[1]), ptr(bhh[1]), ptr(hout), ptr(gates), Hh, Lg, NP, st), "gru_fwd")
+    dgi = torch.empty(6 * Hh, Lg, NP, device=DEV)
+    dghn = torch.empty(2 * Hh, Lg, NP, device=DEV)
+    check(lib.trunet_gru_bwd(ptr(dhout), ptr(hout), ptr(gates), ptr(whh[0]), ptr(whh[1]), ptr(dgi), ptr(dghn), Hh, Lg, NP, NP, st), "gru_bwd")
+    # the bf16-I/O kernels
+    gi16, dh16 = to_oct(gi), to_oct(dhout)
+    hout16 = torch.empty((2 * Hh // 8, Lg, NP, 8), device=DEV, dtype=torch.bfloat16)
+    gates16 = torch.empty((8 * Hh // 8, Lg, NP, 8), device=DEV, dtype=torch.bfloat16)
+    check(lib.trunet_bf16_gru_fwd(ptr16(gi16), ptr(whh[0]), ptr(bhh[0]), ptr(whh[1]), ptr(bhh[1]), ptr16(hout16), ptr16(gates16),
+                                  Hh, Lg, NP, st), "bf16_gru_fwd")
+    dgi16 = torch.empty((6 * Hh // 8, Lg, NP, 8), device=DEV, dtype=torch.bfloat16)
+    dghn16 = torch.empty((2 * Hh // 8, Lg, NP, 8), device=DEV, dtype=torch.bfloat16)
+    check(lib.trunet_bf16_gru_bwd(ptr16(dh16), ptr16(hout16), ptr16(gates16), ptr(whh[0]), ptr(whh[1]), ptr16(dgi16), ptr16(dghn16),
+                                  Hh, Lg, NP, st), "bf16_gru_bwd")
+    torch.cuda.synchronize()
+    a_dgi, a_dghn, a_h = from_oct(dgi16, 6 * Hh), from_oct(dghn16, 2 * Hh), from_oct(hout16, 2 * Hh)
+
+    def dwhh(dgi_, dghn_, h_):
+        """recurrent weight gradient per direction: rows (r, z) from dgi, rows n from dghn, against h of the previous step"""
+        out = []
+        for d in range(2):
+            hd = h_[d * Hh:(d + 1) * Hh].double()
+            prev = torch.zeros_like(hd)
+            if d == 0:
+                prev[:, 1:] = hd[:, :-1]
+            else:
+                prev[:, :-1] = hd[:, 1:]
+            dg = torch.cat([dgi_[d * 3 * Hh:d * 3 * Hh + 2 * Hh], dghn_[d * Hh:(d + 1) * Hh]], 0).double()
+            out.append(torch.einsum("mln,kln->mk", dg, prev))
+        return torch.stack(out)
+
+    e_dgi, e_dghn = _l2(a_dgi, dgi), _l2(a_dghn, dghn)
+    e_w = _l2(dwhh(a_dgi, a_dghn, a_h).float(), dwhh(dgi, dghn, hout).float())
+    msg = "bf16-I/O GRU backward vs the exact fp32 recurrence: dgi %.2e  dghn %.2e  dW_hh %.2e (relative L2)" % (e_dgi, e_dghn, e_w)
+    print(msg)
+    import os
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out")
+    if os.path.isdir(out_dir):
+        open(os.path.join(out_dir, "parity_bf16_gru.txt"), "a").write(msg + "\n")
+    # one bf16 rounding of every stored value is 2^-9 = 2e-3 relative RMS; 16 recurrent steps compound it
+    assert e_dgi < 1.5e-2 and e_dghn < 1.5e-2 and e_w < 1e-2, msg
+
+
 def _pair(cin, seed=0):
     from tinyrecurrentunet_amd.network import TRUNet
     torch.manual_seed(seed)
@@ -703,9 +766,19 @@ def test_bf16_eval_forward_through_the_layer_kernels():
 
 
 def test_bf16_full_size_step_configs2_per_gpu_shape():
-    """BASELINE.json configs[2] per-GPU shape (64 x 4 s pairs = 32,064 frames, C_in = 4): loss and its terms within 1 % of
-    the fp32 HIP step (which test_configs_gpu pins against the fp32 oracle at this size), all gradients finite, and the
-    bf16 step bitwise repeatable"""
+    """BASELINE.json configs[2] per-GPU shape (64 x 4 s pairs = 32,064 frames, C_in = 4), the size the bench runs at.
+    (1) loss and its terms within 1 % of the fp32 HIP step (which test_configs_gpu pins against the fp32 oracle at this size,
+    forward AND all 100 gradient tensors); the bf16 step bitwise repeatable.
+    (2) round 4: EVERY one of the 100 bf16 gradient tensors against the fp32 HIP gradient of the same
+    step -- relative L2 and cosine per tensor -- next to the same two figures for the yardstick "fp32 engine with
+    bf16-rounded weights" (ONE rounding per layer instead of three).  At N <= 501 these deviations are 30-100 % (every
+    perturbation flips ReLU masks and the sums are short); at 32,064 frames the sums are long and the figures below were
+    measured (gpurun_out/parity_fullsize_bf16.txt, copied into DESIGN section 8); the bounds are ~3x the measured values.
+    (3) the forward (training mode, batch statistics) at this size against fp32: relative L2 and the yardstick's."""
+    import os
+    import numpy as np
+    from tinyrecurrentunet_amd import dataset as ds
+    from tinyrecurrentunet_amd.network import TRUNet
     from tinyrecurrentunet_amd.stft_loss import MultiResolutionSTFTLoss
     from tinyrecurrentunet_amd.util import loss_fn
     f32, b16 = _pair(4, seed=4)
@@ -715,23 +788,132 @@ def test_bf16_full_size_step_configs2_per_gpu_shape():
     g.manual_seed(31)
     clean = 0.1 * torch.randn(64, 1, 64000, generator=g, device=DEV)
     noisy = clean + 0.05 * torch.randn(64, 1, 64000, generator=g, device=DEV)
-    l32, d32 = loss_fn(f32, (clean, noisy), 1, 1.0, 1.0, mr)
-    del f32
-    runs = []
-    for _ in range(2):
-        b16.zero_grad(set_to_none=True)
-        for m in b16.modules():
+    feats = ds.stft_features(noisy[:, 0].contiguous(), pcen=True)
+
+    def step(net):
+        net.zero_grad(set_to_none=True)
+        for m in net.modules():
             if isinstance(m, torch.nn.BatchNorm1d):
                 m.reset_running_stats()
-        l16, d16 = loss_fn(b16, (clean, noisy), 1, 1.0, 1.0, mr)
-        l16.backward()
-        runs.append((l16.item(), [p.grad.clone() for n, p in b16.named_parameters() if p.grad is not None]))
-    assert abs(runs[0][0] - l32.item()) < 1e-2 * abs(l32.item()), (runs[0][0], l32.item())
+        loss, info = loss_fn(net, (clean, noisy), 1, 1.0, 1.0, mr)
+        loss.backward()
+        with torch.no_grad():
+            y = net(feats)                       # training-mode forward (batch statistics) without recording
+        return loss.item(), {k: v.item() for k, v in info.items()}, \
+            {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}, y
+
+    l32, d32, g32, y32 = step(f32)
+    del f32
+    torch.cuda.empty_cache()
+    # yardstick: the fp32 engine on weights rounded to bf16 (matrices only, like the bf16 engine's packed images)
+    f32w = TRUNet(input_size=4).cuda().train()
+    f32w.load_state_dict(b16.state_dict())
+    with torch.no_grad():
+        for p in f32w.parameters():
+            if p.dim() > 1:
+                p.copy_(_rb(p))
+    lw, dw, gw, yw = step(f32w)
+    del f32w
+    torch.cuda.empty_cache()
+    runs = [step(b16) for _ in range(2)]
+    l16, d16, g16, y16 = runs[0]
+    assert abs(l16 - l32) < 1e-2 * abs(l32), (l16, l32)
     for k in d32:
-        assert abs(d16[k].item() - d32[k].item()) < 2e-2 * abs(d32[k].item()) + 1e-5, (k, d16[k].item(), d32[k].item())
-    assert sum(t.numel() for t in runs[0][1]) == 298592
-    assert all(torch.isfinite(t).all() for t in runs[0][1])
-    assert runs[0][0] == runs[1][0] and all(torch.equal(a, b) for a, b in zip(runs[0][1], runs[1][1]))
+        assert abs(d16[k] - d32[k]) < 2e-2 * abs(d32[k]) + 1e-5, (k, d16[k], d32[k])
+    assert sum(t.numel() for t in g16.values()) == 298592 and len(g16) == 100
+    assert all(torch.isfinite(t).all() for t in g16.values())
+    assert runs[1][0] == l16 and all(torch.equal(g16[n], runs[1][2][n]) for n in g16)
+    assert torch.equal(y16, runs[1][3])
+    # ---- (3) forward at full size
+    fwd16, fwdw = _l2(y16, y32), _l2(yw, y32)
+    # ---- (2) all 100 gradient tensors
+    rows = []
+    names = dict((n, None) for n in g32)
+    for n in names:
+        r = g32[n]
+        sib = g32[n[:-6] + "bias"].norm().item() if n.endswith(".1.weight") else 0.0
+        tiny = r.norm().item() < 1e-6 * r.numel() ** 0.5 or r.norm().item() < 0.05 * sib
+        scale = max(r.norm().item(), sib if tiny else 0.0) + 1e-30
+
+        def dev(t):
+            cos = (t * r).sum().item() / (t.norm().item() * r.norm().item() + 1e-30)
+            return (t - r).norm().item() / scale, cos
+        rows.append((n, tiny) + dev(g16[n]) + dev(gw[n]))
+    real = [x for x in rows if not x[1]]
+    e16 = np.array([x[2] for x in real]); c16 = np.array([x[3] for x in real])
+    ew = np.array([x[4] for x in real]); cw = np.array([x[5] for x in real])
+    lines = ["bf16 full-size step (N = 32,064) vs the fp32 HIP step; yardstick = fp32 engine with bf16-rounded weights",
+             "forward (training mode) relative L2: bf16 %.3e   yardstick %.3e" % (fwd16, fwdw),
+             "loss: fp32 %.6f  bf16 %.6f  yardstick %.6f" % (l32, l16, lw),
+             "gradients, %d tensors with a non-vanishing fp32 gradient (of %d):" % (len(real), len(rows)),
+             "  bf16      relative L2 median %.3e max %.3e   cosine median %.5f min %.5f" % (
+                 np.median(e16), e16.max(), np.median(c16), c16.min()),
+             "  yardstick relative L2 median %.3e max %.3e   cosine median %.5f min %.5f" % (
+                 np.median(ew), ew.max(), np.median(cw), cw.min()),
+             "  analytically vanishing gradients (%d tensors), deviation relative to the sibling's scale: bf16 max %.3e" % (
+                 len(rows) - len(real), max([x[2] for x in rows if x[1]] + [0.0]))]
+    worst = sorted(real, key=lambda x: -x[2])[:8]
+    lines += ["  %-46s bf16 %.3e (cos %.4f)   yardstick %.3e (cos %.4f)" % (x[0], x[2], x[3], x[4], x[5]) for x in worst]
+    msg = "\n".join(lines)
+    print(msg)
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out")
+    if os.path.isdir(out_dir):
+        open(os.path.join(out_dir, "parity_fullsize_bf16.txt"), "a").write(msg + "\n\n")
+    B_FWD, B_MED, B_MAX, B_COS, B_TINY = BF16_FULLSIZE_BOUNDS
+    assert fwd16 < B_FWD, msg
+    assert np.median(e16) < B_MED and e16.max() < B_MAX and c16.min() > B_COS, msg
+    assert max([x[2] for x in rows if x[1]] + [0.0]) < B_TINY, msg
+
+
+# forward rel. L2, gradient rel. L2 median / max, minimum cosine, vanishing-gradient deviation: ~3x what round 4 measured
+# at N = 32,064 (gpurun_out/parity_fullsize_bf16.txt)
+BF16_FULLSIZE_BOUNDS = (5e-2, 0.5, 1.5, 0.3, 0.5)
+
+
+def test_bf16_200_step_loss_curve_at_8x1s():
+    """200 FusedAdamW steps at B = 8 x 1 s from the same initial weights, fp32 HIP against bf16: both
+    curves fall without diverging (every loss finite, never above 1.5x the start), and end within the stated percentage of
+    each other (measured: see gpurun_out/parity_bf16_curve200.txt; the trajectories are chaotic step by step -- DESIGN
+    section 10 -- so the gate is on where training arrives, over the mean of the last 20 steps)."""
+    import os
+    from tinyrecurrentunet_amd import network as hn, optim
+    from tinyrecurrentunet_amd.stft_loss import MultiResolutionSTFTLoss
+    from tinyrecurrentunet_amd.util import loss_fn
+    mr = MultiResolutionSTFTLoss(fft_sizes=[512, 1024, 2048], hop_sizes=[50, 120, 240], win_lengths=[240, 600, 1200],
+                                 window="hann_window", sc_lambda=0.5, mag_lambda=0.5, band="full").cuda()
+    g = torch.Generator(device=DEV)
+    g.manual_seed(77)
+    B, Ls = 8, 16000
+    c = 0.1 * torch.randn((B, 1, Ls + 1), generator=g, device=DEV)
+    clean = (0.5 * (c[..., 1:] + c[..., :-1])).contiguous()
+    noisy = (clean + 0.05 * torch.randn((B, 1, Ls), generator=g, device=DEV)).contiguous()
+    curves = {}
+    for prec in ("fp32", "bf16"):
+        torch.manual_seed(5)
+        net = hn.TRUNet(input_size=4, precision=prec).cuda().train()
+        opt = optim.FusedAdamW(net.parameters(), lr=1e-3)
+        ls = []
+        for _ in range(200):
+            opt.zero_grad()
+            loss, _ = loss_fn(net, (clean, noisy), 1, 1.0, 1.0, mr)
+            loss.backward()
+            opt.step()
+            ls.append(loss.detach())
+        curves[prec] = [float(v) for v in torch.stack(ls).cpu()]
+    f, b = curves["fp32"], curves["bf16"]
+    tail_f, tail_b = sum(f[-20:]) / 20, sum(b[-20:]) / 20
+    worst = max(abs(x - y) / x for x, y in zip(f, b))
+    msg = ("200 steps at 8 x 1 s, lr 1e-3: fp32 %.4f -> %.4f (last-20 mean %.4f), bf16 %.4f -> %.4f (last-20 mean %.4f); "
+           "largest per-step gap %.2f %%, gap of the last-20 means %.2f %%" % (
+               f[0], f[-1], tail_f, b[0], b[-1], tail_b, 100 * worst, 100 * abs(tail_f - tail_b) / tail_f))
+    print(msg)
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out")
+    if os.path.isdir(out_dir):
+        open(os.path.join(out_dir, "parity_bf16_curve200.txt"), "a").write(msg + "\n")
+    for ls in (f, b):
+        assert all(v == v and v < 1.5 * ls[0] for v in ls), msg          # finite, no divergence
+        assert sum(ls[-20:]) / 20 < 0.6 * ls[0], msg                      # it trains
+    assert abs(tail_f - tail_b) < 0.05 * tail_f, msg
 
 
 def test_bf16_fused_pointwise_backward_matches_separate_launches():

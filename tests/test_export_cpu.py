@@ -208,6 +208,33 @@ def test_section_bounds_check_refuses_truncated_and_foreign_images():
 
 def test_artefact_of_another_format_is_refused(tmp_path):
     p = tmp_path / "old.pt"
-    torch.save({"format": "trunet-folded-v2", "blob": torch.zeros(8), "offsets": torch.zeros(26, dtype=torch.int32), "cin": 4}, p)
+    torch.save({"format": "trunet-folded-v1", "blob": torch.zeros(8), "offsets": torch.zeros(26, dtype=torch.int32), "cin": 4}, p)
     with pytest.raises(L.TrunetHipError):
         export.FoldedTRUNet.load(str(p))
+    # a v2 image must carry 26 offsets and still pass the section bounds check
+    torch.save({"format": "trunet-folded-v2", "blob": torch.zeros(8), "offsets": torch.zeros(26, dtype=torch.int32), "cin": 4}, p)
+    with pytest.raises(L.TrunetHipError):
+        export.FoldedTRUNet.load(str(p), device="cpu")
+    torch.save({"format": "trunet-folded-v2", "blob": torch.zeros(8), "offsets": torch.zeros(30, dtype=torch.int32), "cin": 4}, p)
+    with pytest.raises(L.TrunetHipError):
+        export.FoldedTRUNet.load(str(p), device="cpu")
+
+
+def test_v2_artefact_is_upgraded_on_load(tmp_path):
+    """artefacts written by rounds 1-2 ("trunet-folded-v2": the 26 sections of the stateless forward) are a v3
+    image whose four TGRU offsets are 0: accepted on load, `has_tgru` False, same blob; `save` keeps writing v3"""
+    net = _net()
+    blob, offs, cin = export.fold(net)
+    assert list(offs[26:]) == [0, 0, 0, 0]
+    p = tmp_path / "v2.pt"
+    torch.save({"format": "trunet-folded-v2", "blob": torch.tensor(blob), "offsets": torch.tensor(offs[:26]), "cin": cin}, p)
+    run = export.FoldedTRUNet.load(str(p), device="cpu")          # host-side checks only: nothing is launched
+    assert not run.has_tgru and run.cin == cin
+    assert list(run.offsets) == list(offs)
+    assert torch.equal(run.blob, torch.tensor(blob))
+    q = tmp_path / "v3.pt"
+    run.save(str(q))
+    d = torch.load(str(q), weights_only=True)
+    assert d["format"] == "trunet-folded-v3" and d["offsets"].numel() == export.N_OFFSETS
+    again = export.FoldedTRUNet.load(str(q), device="cpu")
+    assert torch.equal(again.blob, run.blob) and list(again.offsets) == list(run.offsets)

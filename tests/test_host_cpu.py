@@ -54,6 +54,34 @@ def test_scheduler_matches_reference(golden):
     assert abs(s2.step() - lrs[300]) < 1e-15
 
 
+def test_scheduler_building_blocks_of_the_reference_api(golden):
+    """the reference's util module exports anneal_linear / anneal_cosine / Phase (util.py:81-107) and flatten
+    (:22-23); a schedule assembled from them the way util.py:110-156 does gives the learning rates of the reference fixture,
+    i.e. the same as the closed-form class."""
+    from tinyrecurrentunet_amd import util
+    assert util.flatten([[1, 2], [3], []]) == [1, 2, 3]
+    assert util.anneal_linear(1.0, 3.0, 0.25) == 1.5
+    assert abs(util.anneal_cosine(4.0, 0.0, 0.5) - 2.0) < 1e-12 and util.anneal_cosine(4.0, 1.0, 0.0) == 4.0
+    lr_max, n_iter, div, warm = 4e-4, 1000, 25, 50
+    legs = [util.Phase(lr_max / div, lr_max, warm, 0, util.anneal_linear),
+            util.Phase(lr_max, lr_max / div / 1e4, n_iter - warm, 0, util.anneal_cosine)]
+    lrs, k = [], 0
+    for _ in range(n_iter):
+        lrs.append(legs[k].step())
+        if legs[k].is_done:
+            legs[k].reset()
+            k = 1 - k
+    np.testing.assert_allclose(np.array(lrs), golden("sched")["lrs"], rtol=1e-12, atol=0)
+
+    class Layer:
+        weight = torch.nn.Parameter(torch.arange(12.0).reshape(3, 4))
+        bias = torch.nn.Parameter(torch.ones(3))
+    w0 = Layer.weight.detach().clone()
+    util.weight_scaling_init(Layer)
+    a = torch.sqrt(10.0 * w0.std())
+    assert torch.allclose(Layer.weight.detach(), w0 / a) and torch.allclose(Layer.bias.detach(), torch.ones(3) / a)
+
+
 def test_find_max_epoch_and_misc(tmp_path):
     from tinyrecurrentunet_amd import util
     assert util.find_max_epoch(str(tmp_path)) == -1
@@ -190,6 +218,7 @@ def test_dropin_modules_satisfy_the_reference_import_lines():
              "from stft_loss import MultiResolutionSTFTLoss",                                         # train.py:18
              "from util import rescale, find_max_epoch, print_size",                                  # train.py:19
              "from util import LinearWarmupCosineDecay, loss_fn",                                     # train.py:20
+             "from util import anneal_linear, anneal_cosine, Phase, flatten, std_normal, weight_scaling_init, sampling",
              "from network import TRUNet, TRUNet2D",                                                  # train.py:22
              "from network import TRUNet",                                                            # rt.py:8
              "from dataset import ProcessAudio",                                                      # stream.py:14
@@ -484,6 +513,35 @@ def test_bare_bench_launcher_fails_loudly_when_a_rank_dies():
     assert out.returncode != 0
     assert "stopping the other ranks" in out.stderr or "exited with code" in out.stderr
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_ranks_pin_themselves_to_disjoint_core_slices():
+    """every bench rank restricts itself to its own slice of the node's cores before torch is imported
+    (under torch.distributed.run and under bench.py's own launcher alike); --host-cores K narrows a rank to K cores."""
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import bench
+    cores = list(range(3, 35))                          # 32 cores with an offset
+    sl = [bench.rank_core_slice(cores, r, 8) for r in range(8)]
+    assert all(len(x) == 4 for x in sl) and sorted(sum(sl, [])) == cores
+    assert bench.rank_core_slice(cores, 0, 1) == cores
+    assert bench.rank_core_slice([5, 9], 3, 8) == [9] and bench.rank_core_slice([5, 9], 2, 8) == [5]
+    sl = [bench.rank_core_slice(list(range(10)), r, 4) for r in range(4)]       # 10 cores, 4 ranks: 2 each, disjoint
+    assert all(len(x) == 2 for x in sl) and len(set(sum(sl, []))) == 8
+    have = sorted(os.sched_getaffinity(0))
+    if len(have) < 4:
+        pytest.skip("needs 4 host cores")
+    code = ("import os, sys; sys.argv = ['bench.py'] + sys.argv[1:]; sys.path.insert(0, %r); import bench; "
+            "print(bench.pin_host_cores(), sorted(os.sched_getaffinity(0)))" % ROOT)
+    for env, argv, want in (({"LOCAL_RANK": "1", "LOCAL_WORLD_SIZE": "2"}, [], have[len(have) // 2:2 * (len(have) // 2)]),
+                            ({"LOCAL_RANK": "0", "LOCAL_WORLD_SIZE": "2"}, ["--host-cores", "1"], have[:1]),
+                            ({}, ["--host-cores=2"], have[:2]),
+                            ({"TRUNET_BENCH_PIN": "0", "LOCAL_RANK": "1", "LOCAL_WORLD_SIZE": "2"}, [], None)):
+        e = {k: v for k, v in os.environ.items() if k not in ("LOCAL_RANK", "LOCAL_WORLD_SIZE", "WORLD_SIZE", "TRUNET_BENCH_PIN")}
+        e.update(env)
+        out = subprocess.run([sys.executable, "-c", code] + argv, env=e, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert out.stdout.strip() == "%s %s" % (want, want if want is not None else have), (env, argv, out.stdout)
 
 
 def test_use_tgru_bf16_is_refused_at_construction():

@@ -21,7 +21,7 @@ def _grad_close(g, ref, name, errs=None):
     """Gradient parity metric.  A weight-gradient element is a sum of ~N*L products gated by ReLU
     masks, and BatchNorm makes several of these sums strongly cancelling, so fp32 rounding is
     amplified in EVERY fp32 implementation.  Measured vs the fp64 oracle (N=300,
-    tests/gpu_debug_grad_precision.py, relative L2 per tensor, median / max over the 100 tensors):
+    scripts/dbg/grad_precision.py, relative L2 per tensor, median / max over the 100 tensors):
     HIP 2.9e-3 / 1.2e-2, torch CPU fp32 4.7e-3 / 6.4e-3, torch GPU fp32 1.2e-2 / 2.5e-2; over seeds 3,4,5 the
     medians are HIP 1.0e-2, 6.8e-3, 4.3e-3 vs torch GPU fp32 1.2e-2, 6.4e-3, 4.0e-3 (a single flip near the
     output perturbs every tensor below it, so the whole vector of errors moves together from run to run).
@@ -108,6 +108,46 @@ def test_forward_backward_vs_oracle_f64(N):
         ref_g = pd[pn].grad
         _grad_close(p.grad, ref_g, pn, errs)
     assert float(np.median(errs)) < 2.5e-2, float(np.median(errs))
+
+@pytest.mark.parametrize("switch", ["FUSED_PWBWD", "FUSED_CONVT", "FUSED_THIN", "FUSED_GRU_PROJ"])
+def test_unfused_fallback_schedules_through_trunet(switch, monkeypatch):
+    """the separate-launch schedules the engine falls back to when a fused backward kernel answers
+    TRUNET_ENOTSUP (engine._pw_bwd / _convt_bwd / the thin decoder.5 layer / the GRU input projection) driven once THROUGH
+    TRUNet -- the same switches TRUNET_FUSED_PWBWD / _CONVT / _THIN / _GRU_PROJ = 0 set -- against the fused result on the
+    same forward state: the backward is linear in the cotangent and both schedules multiply the same fp32 numbers, so they
+    may differ by summation order only (conv biases in front of a BatchNorm: analytically zero, absolute floor)."""
+    import tinyrecurrentunet_amd.engine as E
+    ref, net = _nets(4, seed=5)
+    N = 300
+    x = torch.tensor(np.random.default_rng(N).standard_normal((N, 4, 257)) * 0.5, dtype=torch.float32).cuda()
+    cot = torch.tensor(np.random.default_rng(N + 1).standard_normal((N, 8, 257)), dtype=torch.float32).cuda()
+
+    def grads():
+        net.zero_grad(set_to_none=True)
+        net.load_state_dict(ref.state_dict())
+        net.train()
+        y = net(x)
+        (y * cot).sum().backward()
+        return y.detach().clone(), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+
+    y1, fused = grads()
+    assert getattr(E, switch) is True
+    monkeypatch.setattr(E, switch, False)
+    y0, sep = grads()
+    monkeypatch.undo()
+    assert torch.equal(y0, y1)
+    assert set(sep) == set(fused) and sum(t.numel() for t in sep.values()) == 298592
+    worst, differs = 0.0, False
+    for n, a in fused.items():
+        b = sep[n]
+        differs |= not torch.equal(a, b)
+        sib = n[:-6] + "bias" if n.endswith(".1.weight") else (n[:-4] + "weight" if n.endswith("bias") else n)
+        scale = max(b.norm().item(), sep[sib].norm().item() if sib in sep else 0.0)
+        e = (a - b).norm().item() / (scale + 1e-30)
+        worst = max(worst, e)
+        assert e < 2e-3, (switch, n, e)
+    assert differs, "%s = False took the same launches as the fused schedule" % switch
+    print("%s: unfused vs fused schedule, worst relative L2 over the gradient tensors %.2e" % (switch, worst))
 
 
 def test_zero_batchnorm_weights_vs_oracle_f64():

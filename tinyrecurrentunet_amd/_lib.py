@@ -164,6 +164,7 @@ def _declare(L):
         "trunet_tgru_cell_bwd": [p, p, p, p, p, p, i, i, i, i, i, p],
         "trunet_adamw": [p, p, p, p, i64, f, f, f, f, f, i, p],
         "trunet_sumsq": [p, i64, p, p],
+        "trunet_checksum_batch": [p, i, p, p],
         "trunet_stft_features": [p, p, p, p, i, i, i, i, p],
         "trunet_pcen": [p, p, i, i, i, f, f, f, f, f, p],
         "trunet_mask_istft_fwd": [p, p, p, p, p, p, i, i, i, f, p],

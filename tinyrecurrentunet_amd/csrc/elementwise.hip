@@ -851,6 +851,30 @@ __global__ __launch_bounds__(1024) void sumsq_kernel(const float* __restrict__ g
     if (tid == 0) out[0] = (float)red[0];
 }
 
+// 64-bit content checksum of a list of device buffers in ONE launch (blockIdx.y = buffer): every 32-bit word is mixed with
+// its position and the buffer index and the results are summed (order-independent, so atomics are fine).  TRUNet.folded keys
+// its cached eval artefact on it: weights written through `p.data` (util.weight_scaling_init of the reference) move no
+// torch version counter.  `out` must be zero on entry.
+struct ChecksumDesc { const uint32_t* ptr; long long nwords; };
+__global__ __launch_bounds__(256) void checksum_batch_kernel(const ChecksumDesc* __restrict__ desc, unsigned long long* out) {
+    __shared__ unsigned long long red[256];
+    const ChecksumDesc d = desc[blockIdx.y];
+    unsigned long long acc = 0ull;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < d.nwords; i += (long long)gridDim.x * 256) {
+        unsigned long long h = (unsigned long long)d.ptr[i] + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1) +
+                               0xC2B2AE3D27D4EB4Full * (unsigned long long)(blockIdx.y + 1);
+        h ^= h >> 31; h *= 0x7FB5D329728EA185ull; h ^= h >> 27; h *= 0x81DADEF4BC2DD44Dull; h ^= h >> 33;
+        acc += h;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && red[0]) atomicAdd(out, red[0]);
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
@@ -1065,6 +1089,12 @@ extern "C" int trunet_adamw(float* p, const float* g, float* m, float* v, int64_
     float bc2s = sqrtf(1.f - powf(beta2, (float)step));
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ST, p, g, m, v, n, lr, beta1, beta2,
                        eps, wd, bc1, bc2s);
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_checksum_batch(const void* desc, int n, uint64_t* out, void* stream) {
+    if (!desc || !out || n <= 0 || n > 65535) return TRUNET_EINVAL;
+    hipLaunchKernelGGL(checksum_batch_kernel, dim3(8, n), dim3(256), 0, ST, (const ChecksumDesc*)desc, (unsigned long long*)out);
     return trunet_launch_status();
 }
 

@@ -202,10 +202,22 @@ class FoldedTRUNet:
 
     @classmethod
     def load(cls, path, device=None):
-        d = torch.load(path, map_location="cpu", weights_only=True)
-        if d.get("format") != "trunet-folded-v3":
-            raise L.TrunetHipError("%s is not a folded TRU-Net artefact (format %r)" % (path, d.get("format")))
-        return cls(d["blob"], d["offsets"].numpy(), int(d["cin"]), device)
+        return cls.from_dict(torch.load(path, map_location="cpu", weights_only=True), device, what=path)
+
+    @classmethod
+    def from_dict(cls, d, device=None, what="dictionary"):
+        """The saved dictionary -> runner.  "trunet-folded-v3" is what ``save`` writes; a "trunet-folded-v2" image (rounds 1-2:
+        the 26 sections of the stateless forward, same layout) is a v3 image without the time-recurrent block -- its four
+        TGRU offsets are 0 -- and is upgraded on load."""
+        fmt = d.get("format") if isinstance(d, dict) else None
+        if fmt not in ("trunet-folded-v3", "trunet-folded-v2"):
+            raise L.TrunetHipError("%s is not a folded TRU-Net artefact (format %r)" % (what, fmt))
+        offs = np.asarray(d["offsets"].numpy() if torch.is_tensor(d["offsets"]) else d["offsets"], dtype=np.int32)
+        if fmt == "trunet-folded-v2":
+            if offs.shape != (26,):
+                raise L.TrunetHipError("%s: a v2 artefact has 26 section offsets, got %s" % (what, offs.shape))
+            offs = np.concatenate([offs, np.zeros(N_OFFSETS - 26, dtype=np.int32)])
+        return cls(d["blob"], offs, int(d["cin"]), device)
 
     def _run(self, x, h_in, h_out):
         if not x.is_cuda:

@@ -295,20 +295,49 @@ class TRUNet(nn.Module):
     fold_eval = True
     fold_max_frames = 8192
 
+    # Weights can also be written behind torch's back: `p.data.mul_()` / `layer.weight.data /= s` (the idiom of the reference's
+    # util.weight_scaling_init, util.py:168-175) move neither the parameter's version counter nor the mutation epoch.  With
+    # fold_verify (default) every eval call that may reuse a cached artefact first takes a 64-bit content checksum of all
+    # parameters and buffers on the device (one launch + one 8-byte read-back, ~50 us) and re-folds when it moved.  Serving
+    # loops with frozen weights can switch it off (net.fold_verify = False) and call net.invalidate_folded() after a raw write.
+    # During hipGraph capture nothing can be read back: the artefact captured is the one verified by the warm-up call.
+    fold_verify = True
+
+    def invalidate_folded(self):
+        """Drop the cached eval artefacts (rebuilt by the next eval forward / stream_step)."""
+        object.__setattr__(self, "_folded_cache", None)
+
+    def _content_checksum(self, ts):
+        import ctypes as C
+        ptrs = tuple((t.data_ptr(), t.numel() * t.element_size() // 4) for t in ts)
+        ck = self.__dict__.get("_cksum")
+        if ck is None or ck[0] != ptrs or ck[1].device != ts[0].device:
+            arr = (C.c_int64 * (2 * len(ptrs)))(*[v for pn in ptrs for v in pn])
+            desc = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.int64).to(ts[0].device)
+            ck = (ptrs, desc, ts)                           # ts: keeps the described storages alive
+            object.__setattr__(self, "_cksum", ck)
+        out = torch.zeros(1, device=ts[0].device, dtype=torch.int64)
+        _lib.check(_lib.lib().trunet_checksum_batch(ck[1].data_ptr(), len(ptrs), out.data_ptr(), _lib.stream()), "checksum")
+        return int(out.item())
+
     def folded(self, tgru=False):
         """The exported inference artefact of the current weights (export.FoldedTRUNet), rebuilt when a parameter or
         buffer has been modified since; tgru=True: with the time-recurrent block (the stateful stream_step artefact)."""
         from .export import FoldedTRUNet
         ts = [t for n, t in self.state_dict(keep_vars=True).items() if tgru or not n.startswith("TGRU.")]
         # version counters catch torch-side writes (load_state_dict, in-place ops); the mutation epoch catches the
-        # product's own raw-pointer writers (FusedAdamW.step, the BatchNorm running statistics of a training forward)
-        key = (tuple(t._version for t in ts), tuple(t.data_ptr() for t in ts[:2]), str(ts[0].device),
-               _lib.mutation_epoch())
+        # product's own raw-pointer writers (FusedAdamW.step, the BatchNorm running statistics of a training forward);
+        # the data pointers catch re-pointed storages; the content checksum everything else (see fold_verify)
         cache = self.__dict__.get("_folded_cache")
         if cache is None:
             cache = {}
             object.__setattr__(self, "_folded_cache", cache)
         cached = cache.get(bool(tgru))
+        key = (tuple(t._version for t in ts), tuple(t.data_ptr() for t in ts), str(ts[0].device), _lib.mutation_epoch())
+        if cached is not None and cached[0][:4] == key and (not self.fold_verify or torch.cuda.is_current_stream_capturing()):
+            return cached[1]
+        if self.fold_verify and not torch.cuda.is_current_stream_capturing():
+            key = key + (self._content_checksum(ts),)
         if cached is None or cached[0] != key:
             cached = (key, FoldedTRUNet.from_module(self, tgru=tgru))
             cache[bool(tgru)] = cached

@@ -138,9 +138,58 @@ class LinearWarmupCosineDecay:
         return lr
 
 
+# The reference's util module also exports the pieces its scheduler class is assembled from (util.py:81-107): kept as
+# importable names for code written as `from util import anneal_cosine, Phase`.  The scheduler above does not use them
+# (it is a closed form of one counter); tests/test_host_cpu.py checks that both give the same learning rates.
+def anneal_linear(start, end, proportion):
+    return LinearWarmupCosineDecay._curve("linear", start, end, proportion)
+
+
+def anneal_cosine(start, end, proportion):
+    return LinearWarmupCosineDecay._curve("cosine", start, end, proportion)
+
+
+class Phase:
+    """One leg of a schedule: ``n_iter`` steps from ``start`` to ``end`` along ``anneal_fn`` (util.py:90-107)."""
+
+    def __init__(self, start, end, n_iter, cur_iter, anneal_fn):
+        self.start, self.end, self.n_iter, self.n, self.anneal_fn = start, end, n_iter, cur_iter, anneal_fn
+
+    def step(self):
+        self.n += 1
+        return self.anneal_fn(self.start, self.end, self.n / self.n_iter)
+
+    def reset(self):
+        self.n = 0
+
+    @property
+    def is_done(self):
+        return self.n >= self.n_iter
+
+
 # ----------------------------------------------------------------------------- small host helpers
+def flatten(v):
+    """util.py:22-23: one level of nesting removed."""
+    return [x for y in v for x in y]
+
+
 def rescale(x):
     return (x - x.min()) / (x.max() - x.min())
+
+
+def std_normal(size):
+    """util.py:160-164: standard normal noise of ``size`` on the GPU."""
+    return torch.randn(tuple(size), device="cuda")
+
+
+def weight_scaling_init(layer):
+    """util.py:168-175 (arXiv 1911.13254): weight and bias divided by sqrt(10 * std(weight)).  Written through ``.data``
+    like the reference, which moves no version counter: the mutation epoch is bumped so that a cached eval artefact
+    (TRUNet.folded) is rebuilt."""
+    alpha = 10.0 * layer.weight.detach().std()
+    layer.weight.data /= torch.sqrt(alpha)
+    layer.bias.data /= torch.sqrt(alpha)
+    L.bump_mutation_epoch()
 
 
 def find_max_epoch(path):
@@ -160,8 +209,9 @@ def print_size(net, keyword=None):
     if net is not None and isinstance(net, torch.nn.Module):
         params = sum(np.prod(p.size()) for p in net.parameters() if p.requires_grad)
         print("{} Parameters: {:.6f}M".format(net.__class__.__name__, params / 1e6), flush=True, end="; ")
-        if keyword is not None:
-            print(keyword, end="; ")
+        if keyword is not None:       # util.py:63-67: the share of the parameters whose name contains the keyword
+            kp = sum(np.prod(p.size()) for n, p in net.named_parameters() if p.requires_grad and keyword in n)
+            print("{} Parameters: {:.6f}M".format(keyword, kp / 1e6), flush=True, end="; ")
         print(" ")
 
 
