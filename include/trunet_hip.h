@@ -62,6 +62,8 @@ enum { TRUNET_EPI_BIAS = 1,   /* add bias[m]                                    
        TRUNET_EPI_ACCUM = 4,  /* add the value already stored at the output location               */
        TRUNET_EPI_MASK = 8,   /* multiply by [e0[m]*zmask + e1[m] > 0] (ReLU backward)              */
        TRUNET_EPI_RELU = 16,  /* max(.,0) before the store                                          */
+       TRUNET_EPI_PREZERO = 64, /* with STATS: `partials` is already zero (trunet_bn_finalize_* leave the rows they consumed
+                                   zero): the entry point skips its own zero-fill launch */
        TRUNET_EPI_F32OUT = 32 /* trunet_bf16_gemm only: `out` is an fp32 frames-last tensor [rows][out_L][NP] (the GRU input
                                  projection, whose consumer is the fp32 recurrence); with BIAS only               */ };
 
@@ -137,7 +139,8 @@ int trunet_conv_wgrad(const trunet_wgrad_args* h_args, void* stream);
 enum { TRUNET_DG_STORE = 1,  /* write the data gradient of this segment to `out`          */
        TRUNET_DG_MASK = 2,   /* ReLU backward: multiply by [e0*zmask + e1 > 0]             */
        TRUNET_DG_STATS = 4,  /* BatchNorm-backward statistics of the source (needs MASK)   */
-       TRUNET_DG_ACCUM = 8   /* add the value already stored in `out` before masking       */ };
+       TRUNET_DG_ACCUM = 8,  /* add the value already stored in `out` before masking       */
+       TRUNET_DG_PREZERO = 16 /* with STATS: `partials` is already zero (see TRUNET_EPI_PREZERO) */ };
 typedef struct {
     float* out;            /* [nchan][seg.L][NP] */
     const float* zmask;    /* raw tensor of the source, same shape: must BE the segment's src0 (the kernel takes the mask
@@ -187,7 +190,7 @@ int trunet_reduce_partials(float* out, const float* partials, int nparts, int nu
  * partials: [nparts][C][2] = sum, sumsq.  Writes scale = gamma*rstd, shift = beta - mean*scale,
  * mean, rstd; updates running_mean / running_var in place when non-NULL and adds 1 to the int64 counter
  * num_batches_tracked (BatchNorm1d's buffer) when non-NULL. */
-int trunet_bn_finalize_fwd(const float* partials, int nparts, int C, double count, const float* gamma,
+int trunet_bn_finalize_fwd(float* partials, int nparts, int C, double count, const float* gamma,
                            const float* beta, float eps, float momentum, float* running_mean,
                            float* running_var, float* scale, float* shift, float* mean, float* rstd,
                            int64_t* num_batches_tracked, void* stream);
@@ -196,7 +199,7 @@ int trunet_bn_eval_affine(int C, const float* gamma, const float* beta, const fl
                           const float* running_var, float eps, float* scale, float* shift, void* stream);
 /* BatchNorm backward reduction: partials [nparts][C][2] = sum(dy), sum(dy*(z-mean)).
  * Writes dgamma, dbeta and the coefficients of dz = ca*dy + cb*z + cc. */
-int trunet_bn_finalize_bwd(const float* partials, int nparts, int C, double count, const float* gamma,
+int trunet_bn_finalize_bwd(float* partials, int nparts, int C, double count, const float* gamma,
                            const float* mean, const float* rstd, float* dgamma, float* dbeta, float* ca,
                            float* cb, float* cc, void* stream);
 
@@ -330,6 +333,39 @@ int trunet_stft_loss_fwd(const float* x, const float* y, const float* win, const
  * the window's support, centred in n) and a gather sums them per sample; gx is written (not accumulated), deterministic. */
 int trunet_stft_loss_bwd_gather(const float* x, const float* y, const float* win, const float* tw, const float* coef,
                                 float* frames, float* gx, int B, int L, int n, int hop, int win_length, void* stream);
+/* ---- the train step's loss as util.loss_fn composes it (util.py:239-250, stft_loss.py:141-166), fused (round 4) ----
+ * trunet_stft_loss_fwdgrad: trunet_stft_loss_fwd's three sums per frame AND the two coefficient-free gradient frames of the
+ * same resolution (fr_sc, fr_mag: (B, frames, win_length)) from one pass: the gradient of a resolution is
+ * c_sc * OLA(fr_sc) + c_mag * OLA(fr_mag) with coefficients known only after the grid-wide sums. */
+int trunet_stft_loss_fwdgrad(const float* x, const float* y, const float* win, const float* tw, float* partials,
+                             float* fr_sc, float* fr_mag, int B, int L, int n, int hop, int win_length, void* stream);
+#define TRUNET_MAX_RES 8
+typedef struct trunet_loss_args {
+    const float* l1_partials;              /* trunet_mask_istft_fwd's per-block sums of |audio - clean| */
+    const float* parts[TRUNET_MAX_RES];    /* per resolution: (nrows, 3) sums of trunet_stft_loss_fwd(grad) */
+    int32_t n_l1, nres;
+    int32_t nrows[TRUNET_MAX_RES];         /* B * frames */
+    double l1_count;                       /* B * L */
+    double count[TRUNET_MAX_RES];          /* B * frames * (n/2 + 1) */
+    float sc_lambda, mag_lambda, stft_lambda, _pad;
+} trunet_loss_args;
+/* One launch: every column sum in fp64 and the scalar algebra of util.py:239-250 / stft_loss.py:151-166:
+ * loss_out[0] = l1 + stft_lambda * (sc_lambda * sum_i sqrt(S1_i)/sqrt(S2_i) + mag_lambda * sum_i S3_i/count_i) / nres;
+ * vals (>= 5 + 2 nres floats): [0] loss [1] l1 [2] stft_sc term [3] stft_mag term [4] 1/(B L) [5+2i] c_sc_i [6+2i] c_mag_i
+ * (the backward coefficients for an upstream gradient of 1).  scratch: trunet_loss_scratch_bytes() bytes, ZERO on first use
+ * (the kernel leaves it zero). */
+size_t trunet_loss_scratch_bytes(void);
+int trunet_loss_finalize(const trunet_loss_args* a, float* loss_out, float* vals, void* scratch, void* stream);
+typedef struct trunet_loss_gather_args {
+    const float* fr_sc[TRUNET_MAX_RES];
+    const float* fr_mag[TRUNET_MAX_RES];
+    int32_t n[TRUNET_MAX_RES], hop[TRUNET_MAX_RES], win_length[TRUNET_MAX_RES];
+    int32_t nres, _pad;
+} trunet_loss_gather_args;
+/* d loss / d audio (B, L) in one deterministic gather: g_loss[0] * (vals[4] * sign(audio - clean) + sum_i (vals[5+2i] *
+ * OLA_i(fr_sc_i) + vals[6+2i] * OLA_i(fr_mag_i))) -- autograd of nn.L1Loss (util.py:239) + stft_loss.py:9-113. */
+int trunet_loss_grad_gather(const trunet_loss_gather_args* a, const float* audio, const float* clean, const float* vals,
+                            const float* g_loss, float* g_audio, int B, int L, void* stream);
 /* stft() of stft_loss.py:9-30: magnitudes sqrt(clamp(re^2+im^2, 1e-7)) of the Hann-windowed, centre/reflect-padded STFT
  * as (B, 1 + L/hop, n/2 + 1); y / ymag may be NULL (one signal), else both signals share one complex FFT. */
 int trunet_stft_mag(const float* x, const float* y, const float* win, const float* tw, float* xmag, float* ymag, int B,
@@ -461,6 +497,7 @@ int trunet_bf16_pw_bwd(const trunet_bpwbwd_args* h_args, void* stream);
  * 0, K, {64,..}, {0..K-1}).  Ci = Co = 64, (K, S) in {(3,1), (5,2), (3,2)}, pad = S/2 (else TRUNET_ENOTSUP). */
 typedef struct {
     int32_t NP, N, Lin, Lout, K, S, pad, Ci, Co, w_numel, b_stride, b_off;
+    int32_t prezero, _pad;    /* prezero != 0: `partials` is already zero (see TRUNET_EPI_PREZERO) */
     const void* dy; const void* z; const float* ca; const float* cb; const float* cc;
     const void* src; const float* s_scale; const float* s_shift; const float* s_mean;
     const void* wfragT; void* dsrc; float* partials; float* w_partials; float* b_partials;

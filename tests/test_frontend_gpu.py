@@ -159,6 +159,96 @@ def test_denoise_and_grad_vs_oracle(B, L):
     assert _rel(og.grad, o64.grad) < 1e-3
 
 
+@pytest.mark.parametrize("B,L,stft_lambda", [(2, 4096, 1.0), (3, 16000, 0.7), (2, 8192, 0.0), (5, 6400, 1.0)])
+def test_fused_loss_node_vs_oracle_and_vs_the_composition(B, L, stft_lambda):
+    """Round 4: util._FusedLossFn (mask + iSTFT + L1 + multi-resolution STFT loss as one autograd node: forward-and-gradient
+    frames in one pass per resolution, one launch for all sums and the scalar algebra, one gather for d loss / d audio)
+    against (a) the fp64 oracle composition (features_ref.denoise_from_output + stft_loss_ref, util.py:239-250) and (b) the
+    composition of the stand-alone HIP pieces (util.denoise + MultiResolutionSTFTLoss, TRUNET_FUSED_LOSS=0), which it must
+    reproduce to fp32 rounding: loss, its three terms, and the gradient with respect to the net output.  A non-unit upstream
+    gradient checks the device-side scaling; L = 6400 gives frame counts that are not multiples of anything."""
+    from oracle import features_ref as fr, stft_loss_ref as slr
+    from tinyrecurrentunet_amd import stft_loss as sl, util
+    T = 1 + L // 128
+    rng = np.random.default_rng(B * L + 1)
+    out = torch.tensor(rng.standard_normal((B * T, 8, 257)) * 0.7, dtype=torch.float32)
+    clean = torch.tensor(rng.standard_normal((B, L)) * 0.1, dtype=torch.float32)
+    # (a) fp64 oracle
+    o64 = out.double().requires_grad_(True)
+    den64 = fr.denoise_from_output(o64, T, 0.5, length=L)
+    l164 = (den64 - clean.double()).abs().mean()
+    loss64 = l164
+    if stft_lambda > 0:
+        sc64, mag64 = slr.mr_stft_loss(den64, clean.double())
+        loss64 = loss64 + (sc64 + mag64) * stft_lambda
+    (2.5 * loss64).backward()
+    mr = sl.MultiResolutionSTFTLoss(**CFG).cuda()
+    cg = clean.cuda()
+    # (b) composition of the stand-alone pieces
+    oc = out.cuda().requires_grad_(True)
+    den, l1 = util.denoise(oc, cg, T)
+    loss_c = torch.abs(l1)
+    if stft_lambda > 0:
+        sc_c, mag_c = mr(den, cg)
+        loss_c = loss_c + (sc_c + mag_c) * stft_lambda
+    (2.5 * loss_c).backward()
+    # fused node
+    plan = util._fused_loss_plan(mr, stft_lambda, oc.device)
+    assert plan is not None and len(plan) == (3 if stft_lambda > 0 else 0)
+    of = out.cuda().requires_grad_(True)
+    loss_f, vals = util._FusedLossFn.apply(of, cg, T, 0.5, float(stft_lambda), plan, 0.5, 0.5)
+    assert not vals.requires_grad
+    (2.5 * loss_f).backward()
+    assert abs(float(loss_f) - float(loss64)) < 1e-4 * abs(float(loss64)), (float(loss_f), float(loss64))
+    assert abs(float(loss_f) - float(loss_c)) < 2e-6 * abs(float(loss_c)), (float(loss_f), float(loss_c))
+    assert float(vals[0]) == float(loss_f)
+    assert abs(float(vals[1]) - float(l164)) < 1e-5 * float(l164)
+    if stft_lambda > 0:
+        assert abs(float(vals[2]) - float(sc64) * stft_lambda) < 1e-4 * float(sc64) * stft_lambda
+        assert abs(float(vals[3]) - float(mag64) * stft_lambda) < 1e-4 * float(mag64) * stft_lambda
+        assert abs(float(vals[2]) - float(sc_c) * stft_lambda) < 2e-6 * float(sc_c) * stft_lambda
+    assert _rel(of.grad, o64.grad) < 1e-3, _rel(of.grad, o64.grad)
+    assert _rel(of.grad, oc.grad) < 2e-5, _rel(of.grad, oc.grad)
+    # without a gradient request the forward-only kernels run: same loss bits
+    with torch.no_grad():
+        loss_n, _ = util._FusedLossFn.apply(out.cuda(), cg, T, 0.5, float(stft_lambda), plan, 0.5, 0.5)
+    assert float(loss_n) == float(loss_f)
+    # repeated: the counter in the scratch buffer is left at zero
+    of2 = out.cuda().requires_grad_(True)
+    loss_2, _ = util._FusedLossFn.apply(of2, cg, T, 0.5, float(stft_lambda), plan, 0.5, 0.5)
+    (2.5 * loss_2).backward()
+    assert float(loss_2) == float(loss_f) and torch.equal(of2.grad, of.grad)
+
+
+def test_loss_fn_takes_the_composition_for_foreign_loss_modules(monkeypatch):
+    """loss_fn uses the fused node only for our own MultiResolutionSTFTLoss with band "full"; any other callable (a
+    subclass, a wrapper) and TRUNET_FUSED_LOSS=0 take the composition -- same loss"""
+    from oracle import network_ref as nr, weights as W
+    from tinyrecurrentunet_amd import network as hn, stft_loss as sl, util
+    B, L = 2, 8192
+    clean, noisy = W.synth_pairs(B, L, seed=9)
+    net = hn.TRUNet(input_size=4)
+    net.load_state_dict(W.fill_state_dict(nr.TRUNet(input_size=4), seed=1).state_dict())
+    net.cuda().train()
+    mr = sl.MultiResolutionSTFTLoss(**CFG).cuda()
+
+    class Wrapped(sl.MultiResolutionSTFTLoss):
+        pass
+    X = (clean.cuda(), noisy.cuda())
+    losses, grads = [], []
+    for fused, m in ((True, mr), (False, mr), (True, Wrapped(**CFG).cuda())):
+        monkeypatch.setattr(util, "FUSED_LOSS", fused)
+        assert (util._fused_loss_plan(m, 1.0, torch.device("cuda")) is not None) == (fused and m is mr)
+        net.zero_grad(set_to_none=True)
+        loss, info = util.loss_fn(net, X, ell_p=1, ell_p_lambda=1, stft_lambda=1, mrstftloss=m)
+        loss.backward()
+        assert set(info) == {"l1", "stft_sc", "stft_mag"}
+        losses.append(float(loss))
+        grads.append(net.decoder[5].LastTrCNN[3].weight.grad.clone())
+    assert abs(losses[0] - losses[1]) < 2e-6 * abs(losses[1]) and losses[1] == losses[2]
+    assert _rel(grads[0], grads[1]) < 1e-4 and torch.equal(grads[1], grads[2])
+
+
 def test_loss_fn_end_to_end_vs_oracle():
     """Whole train-step loss (R7) and its parameter gradients vs the oracle composition."""
     from oracle import loss_ref, network_ref as nr, weights as W

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("TRUNET_HIP_LIB") or os.path.join(_HERE, "csrc", "libt
 MAX_SEG = 5
 TRUNET_OK, TRUNET_EINVAL, TRUNET_ELAUNCH, TRUNET_ENOTSUP = 0, -1, -2, -3
 PRO_NONE, PRO_BNRELU, PRO_BNBWD = 0, 1, 2
-EPI_BIAS, EPI_STATS, EPI_ACCUM, EPI_MASK, EPI_RELU, EPI_F32OUT = 1, 2, 4, 8, 16, 32
+EPI_BIAS, EPI_STATS, EPI_ACCUM, EPI_MASK, EPI_RELU, EPI_F32OUT, EPI_PREZERO = 1, 2, 4, 8, 16, 32, 64
 
 _fp = C.c_void_p
 
@@ -46,7 +46,7 @@ class WgradArgs(C.Structure):
                 ("seg", Seg * MAX_SEG)]
 
 
-DG_STORE, DG_MASK, DG_STATS, DG_ACCUM = 1, 2, 4, 8
+DG_STORE, DG_MASK, DG_STATS, DG_ACCUM, DG_PREZERO = 1, 2, 4, 8, 16
 
 
 class DgradOut(C.Structure):
@@ -101,9 +101,25 @@ class BPwBwdArgs(C.Structure):
 
 class BConvtArgs(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("NP", "N", "Lin", "Lout", "K", "S", "pad", "Ci", "Co", "w_numel", "b_stride",
-                                         "b_off")] + \
+                                         "b_off", "prezero", "_pad")] + \
                [(n, _fp) for n in ("dy", "z", "ca", "cb", "cc", "src", "s_scale", "s_shift", "s_mean", "wfragT", "dsrc",
                                    "partials", "w_partials", "b_partials")]
+
+
+MAX_RES = 8
+
+
+class LossArgs(C.Structure):
+    """trunet_loss_args"""
+    _fields_ = [("l1_partials", _fp), ("parts", _fp * MAX_RES), ("n_l1", C.c_int32), ("nres", C.c_int32),
+                ("nrows", C.c_int32 * MAX_RES), ("l1_count", C.c_double), ("count", C.c_double * MAX_RES),
+                ("sc_lambda", C.c_float), ("mag_lambda", C.c_float), ("stft_lambda", C.c_float), ("_pad", C.c_float)]
+
+
+class LossGatherArgs(C.Structure):
+    """trunet_loss_gather_args"""
+    _fields_ = [("fr_sc", _fp * MAX_RES), ("fr_mag", _fp * MAX_RES), ("n", C.c_int32 * MAX_RES), ("hop", C.c_int32 * MAX_RES),
+                ("win_length", C.c_int32 * MAX_RES), ("nres", C.c_int32), ("_pad", C.c_int32)]
 
 
 _lib = None
@@ -174,6 +190,10 @@ def _declare(L):
         "trunet_reduce_cols": [p, i, i, p, p],
         "trunet_stft_loss_fwd": [p, p, p, p, p, i, i, i, i, p],
         "trunet_stft_mag": [p, p, p, p, p, p, i, i, i, i, p],
+        "trunet_stft_loss_fwdgrad": [p, p, p, p, p, p, p, i, i, i, i, i, p],
+        "trunet_loss_scratch_bytes": [],
+        "trunet_loss_finalize": [C.POINTER(LossArgs), p, p, p, p],
+        "trunet_loss_grad_gather": [C.POINTER(LossGatherArgs), p, p, p, p, p, i, i, p],
         "trunet_stft_loss_bwd_gather": [p, p, p, p, p, p, p, i, i, i, i, i, p],
         "trunet_stft_mag_bwd": [p, p, p, p, p, p, i, i, i, i, i, p],
         "trunet_phm_fwd": [p, p, p, i64, f, p],
@@ -208,6 +228,7 @@ def _declare(L):
         fn.argtypes = args
         fn.restype = C.c_int
     L.trunet_stream_fwd_scratch_floats.restype = C.c_size_t
+    L.trunet_loss_scratch_bytes.restype = C.c_size_t
     L._declared = sorted(sig)
 
 

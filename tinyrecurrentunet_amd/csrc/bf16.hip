@@ -1129,8 +1129,13 @@ static bool bseg_ok(const trunet_bseg& sg) {
     return true;
 }
 
-extern "C" int trunet_bf16_gemm(const trunet_bgemm_args* h, void* stream) {
-    if (!h || !h->out || !h->wfrag || h->nseg < 1 || h->nseg > TRUNET_MAX_SEG) return TRUNET_EINVAL;
+extern "C" int trunet_bf16_gemm(const trunet_bgemm_args* h_in, void* stream) {
+    if (!h_in) return TRUNET_EINVAL;
+    trunet_bgemm_args hcopy = *h_in;                 // the template dispatch below compares `epi` exactly
+    const bool prezero = (hcopy.epi & TRUNET_EPI_PREZERO) != 0;
+    hcopy.epi &= ~TRUNET_EPI_PREZERO;
+    const trunet_bgemm_args* h = &hcopy;
+    if (!h->out || !h->wfrag || h->nseg < 1 || h->nseg > TRUNET_MAX_SEG) return TRUNET_EINVAL;
     if (h->NP <= 0 || (h->NP % 64) != 0 || h->N <= 0 || h->N > h->NP || h->P <= 0 || h->M <= 0) return TRUNET_EINVAL;
     if (h->M > 128 || h->nks_total <= 0 || h->nks_total > BG_MAXKS) return TRUNET_ENOTSUP;
     if (h->out_L <= 0 || h->p_begin < 0 || h->p_begin + h->out_pos_off < 0 || h->p_begin + h->P + h->out_pos_off > h->out_L)
@@ -1144,7 +1149,7 @@ extern "C" int trunet_bf16_gemm(const trunet_bgemm_args* h, void* stream) {
         if (!bseg_ok(sg) || sg.kstep0 < 0) return TRUNET_EINVAL;
         if (sg.kstep0 + (((sg.nchan + 7) / 8 + 1) / 2) > h->nks_total) return TRUNET_EINVAL;
     }
-    if (h->epi & TRUNET_EPI_STATS) {
+    if ((h->epi & TRUNET_EPI_STATS) && !prezero) {
         if (hipMemsetAsync(h->partials, 0, (size_t)trunet_bf16_gemm_nparts() * h->M_stat * 2 * sizeof(float), ST) != hipSuccess)
             return TRUNET_ELAUNCH;
     }
@@ -1305,7 +1310,7 @@ extern "C" int trunet_bf16_pw_bwd(const trunet_bpwbwd_args* H, void* stream) {
                        (size_t)nrt_total * nks * 64 * 16;
     if (lds > 160 * 1024) return TRUNET_ENOTSUP;
     for (int s = 0; s < h->nseg; ++s)
-        if (d->flags[s] & 4)
+        if ((d->flags[s] & 4) && !(d->flags[s] & TRUNET_DG_PREZERO))
             if (hipMemsetAsync(d->partials[s], 0, (size_t)trunet_bf16_pw_bwd_nparts() * h->seg[s].nchan * 2 * sizeof(float), ST) !=
                 hipSuccess)
                 return TRUNET_ELAUNCH;

@@ -246,7 +246,8 @@ extern "C" int trunet_bf16_convt_bwd(const trunet_bconvt_args* h, void* stream) 
     if (!((K == 3 && S == 1) || (K == 5 && S == 2) || (K == 3 && S == 2))) return TRUNET_ENOTSUP;
     const int R = (K + S <= 4) ? 4 : 8;
     const size_t lds = (size_t)(R + 4) * 8 * BW_OS + (size_t)(8 * 24 + 8 * 16 + 64) * sizeof(float) + (size_t)2 * 4 * K * 64 * 16;
-    if (hipMemsetAsync(h->partials, 0, (size_t)trunet_bf16_convt_bwd_nparts() * 64 * 2 * sizeof(float), ST) != hipSuccess)
+    if (!h->prezero &&
+        hipMemsetAsync(h->partials, 0, (size_t)trunet_bf16_convt_bwd_nparts() * 64 * 2 * sizeof(float), ST) != hipSuccess)
         return TRUNET_ELAUNCH;
 #define BCT_LAUNCH(KK, SS)                                                                                                          \
     do {                                                                                                                            \

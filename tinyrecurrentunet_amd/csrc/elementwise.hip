@@ -743,7 +743,9 @@ __global__ __launch_bounds__(256) void tgru_cell_bwd_kernel(float* dhs, const fl
 }
 
 // ---------------------------------------------------------------- BatchNorm statistics -> affine
-__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __restrict__ partials, int nparts, int C,
+// (both finalize kernels leave the partial rows they consumed ZERO: a producer that is told so -- TRUNET_EPI_PREZERO /
+// TRUNET_DG_PREZERO -- needs no zero-fill launch of its own for the rows its idle workgroups do not write)
+__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(float* __restrict__ partials, int nparts, int C,
                                                               double count, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float eps, float momentum,
                                                               float* running_mean, float* running_var, float* scale,
@@ -753,8 +755,11 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __res
     const int c = blockIdx.x;
     double a = 0.0, b = 0.0;
     for (int g = threadIdx.x; g < nparts; g += 256) {
-        a += (double)partials[((size_t)g * C + c) * 2 + 0];
-        b += (double)partials[((size_t)g * C + c) * 2 + 1];
+        f32x2* pp = (f32x2*)(partials + ((size_t)g * C + c) * 2);
+        const f32x2 v = *pp;
+        a += (double)v[0];
+        b += (double)v[1];
+        *pp = f32x2{0.f, 0.f};
     }
     a = block_sum_f64(a, red);
     b = block_sum_f64(b, red);
@@ -786,7 +791,7 @@ __global__ void bn_eval_affine_kernel(int C, const float* gamma, const float* be
     shift[c] = beta[c] - rm[c] * sc;
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __restrict__ partials, int nparts, int C,
+__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(float* __restrict__ partials, int nparts, int C,
                                                               double count, const float* __restrict__ gamma,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
                                                               float* dgamma, float* dbeta, float* ca, float* cb, float* cc) {
@@ -794,8 +799,11 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __res
     const int c = blockIdx.x;
     double a = 0.0, b = 0.0;
     for (int g = threadIdx.x; g < nparts; g += 256) {
-        a += (double)partials[((size_t)g * C + c) * 2 + 0];
-        b += (double)partials[((size_t)g * C + c) * 2 + 1];
+        f32x2* pp = (f32x2*)(partials + ((size_t)g * C + c) * 2);
+        const f32x2 v = *pp;
+        a += (double)v[0];
+        b += (double)v[1];
+        *pp = f32x2{0.f, 0.f};
     }
     a = block_sum_f64(a, red);   // sum dy
     b = block_sum_f64(b, red);   // sum dy*(z-mean)
@@ -1054,7 +1062,7 @@ extern "C" int trunet_relu_bwd_stats(float* dy, const float* z, const float* sca
     return trunet_launch_status();
 }
 
-extern "C" int trunet_bn_finalize_fwd(const float* partials, int nparts, int C, double count, const float* gamma,
+extern "C" int trunet_bn_finalize_fwd(float* partials, int nparts, int C, double count, const float* gamma,
                                       const float* beta, float eps, float momentum, float* running_mean,
                                       float* running_var, float* scale, float* shift, float* mean, float* rstd,
                                       int64_t* num_batches_tracked, void* stream) {
@@ -1073,7 +1081,7 @@ extern "C" int trunet_bn_eval_affine(int C, const float* gamma, const float* bet
     return trunet_launch_status();
 }
 
-extern "C" int trunet_bn_finalize_bwd(const float* partials, int nparts, int C, double count, const float* gamma,
+extern "C" int trunet_bn_finalize_bwd(float* partials, int nparts, int C, double count, const float* gamma,
                                       const float* mean, const float* rstd, float* dgamma, float* dbeta, float* ca,
                                       float* cb, float* cc, void* stream) {
     if (!partials || !gamma || !mean || !rstd || !dgamma || !dbeta || !ca || !cb || !cc) return TRUNET_EINVAL;

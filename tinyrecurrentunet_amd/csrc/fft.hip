@@ -472,6 +472,187 @@ __global__ __launch_bounds__(256) void stft_loss_fwd_kernel(const float* __restr
     }
 }
 
+// Forward AND gradient frames of one resolution in one pass (round 4; the train-step path of util.loss_fn).  The loss of one
+// resolution is sc = sqrt(S1) / sqrt(S2), mag = S3 / count, so its gradient with respect to a bin's magnitude xm is
+//   c_sc (xm - ym) + c_mag sign(log xm - log ym) / xm,   c_sc = g lam_sc / (nres sqrt(S1) sqrt(S2)),  c_mag = g lam_mag / (nres count):
+// LINEAR in two coefficients that are only known after the grid-wide sums.  So the block that has the frame's spectrum in
+// LDS anyway also forms the two coefficient-free gradient half spectra Gs = (xm - ym) X / xm and Gm = sign(.) X / xm^2,
+// sends BOTH through ONE inverse FFT (two real sequences share a complex transform: Z = Herm(Gs) + j Herm(Gm)) and writes the
+// two windowed frames; the backward of the step is then a gather of c_sc * fr_sc + c_mag * fr_mag (loss_grad_gather_kernel)
+// instead of a second kernel that stages the frame and runs the forward FFT again (stft_bwd_kernel: 0.76 of the 1.37 ms the
+// three resolutions took per step).  Same reductions, in the same order, as stft_loss_fwd_kernel: the sums are bit-identical.
+template <int NI>
+__global__ __launch_bounds__(256) void stft_loss_fwdgrad_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                const float* __restrict__ win, const cpx* __restrict__ tw,
+                                                                float* __restrict__ partials, float* __restrict__ fr_sc,
+                                                                float* __restrict__ fr_mag, int L, int n, int logn, int hop,
+                                                                int nframes, int wl, int left) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    cpx* sa = (cpx*)smraw;
+    cpx* sb = sa + n;
+    cpx* stw = sb + n;
+    __shared__ double red[12];
+    const int f = blockIdx.x, b = blockIdx.y;
+    const float* xb = x + (size_t)b * L;
+    const float* yb = y + (size_t)b * L;
+    stft_stage_frame<NI, false>(sa, stw, xb, yb, win, tw, f, hop, n, L);
+    cpx* Z = fft_lds_ni<NI, false>(sa, sb, n, logn, stw);
+    cpx* other = (Z == sa) ? sb : sa;
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int k = threadIdx.x; k <= n / 2; k += 256) {
+        cpx X, Y;
+        split_pair(Z, k, n, X, Y);
+        const float px = X.x * X.x + X.y * X.y;
+        const float xm = sqrtf(fmaxf(px, 1e-7f));   // stft_loss.py:30
+        const float ym = sqrtf(fmaxf(Y.x * Y.x + Y.y * Y.y, 1e-7f));
+        const float d = ym - xm;
+        s1 = fmaf(d, d, s1);
+        s2 = fmaf(ym, ym, s2);
+        const float dl = logf(xm) - logf(ym);
+        s3 += fabsf(-dl);
+        cpx Gs = make_float2(0.f, 0.f), Gm = Gs;
+        if (px > 1e-7f) {       // clamp(min=1e-7) passes no gradient below the floor
+            const float sg = (dl > 0.f) ? 1.f : ((dl < 0.f) ? -1.f : 0.f);
+            const float gs = xm - ym, gm = sg / xm;
+            Gs = make_float2(gs * X.x / xm, gs * X.y / xm);
+            Gm = make_float2(gm * X.x / xm, gm * X.y / xm);
+        }
+        // a[i] = Re sum_{k <= n/2} Gs[k] w^{ki} as the inverse transform of its Hermitian extension A (A[k] = Gs[k] / 2,
+        // A[n-k] = conj(Gs[k]) / 2, A[0] = Re Gs[0], A[n/2] = Re Gs[n/2]); the same for Gm -> B; Z' = A + j B
+        if (k == 0 || k == n / 2) {
+            other[k] = make_float2(Gs.x, Gm.x);
+        } else {
+            other[k] = make_float2(0.5f * (Gs.x - Gm.y), 0.5f * (Gs.y + Gm.x));
+            other[n - k] = make_float2(0.5f * (Gs.x + Gm.y), 0.5f * (-Gs.y + Gm.x));
+        }
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[wave * 3 + 0] = (double)s1; red[wave * 3 + 1] = (double)s2; red[wave * 3 + 2] = (double)s3; }
+    const cpx* g = fft_lds_ni<NI, true>(other, Z, n, logn, stw);          // (begins and ends with a barrier)
+    if (threadIdx.x < 3) {
+        float* pp = partials + ((size_t)b * nframes + f) * 3;
+        pp[threadIdx.x] = (float)((red[threadIdx.x] + red[3 + threadIdx.x]) + (red[6 + threadIdx.x] + red[9 + threadIdx.x]));
+    }
+    const size_t fo = ((size_t)b * nframes + f) * wl;
+    for (int i = threadIdx.x; i < wl; i += 256) {
+        const float w = win[left + i];
+        const cpx v = g[left + i];
+        fr_sc[fo + i] = w * v.x;
+        fr_mag[fo + i] = w * v.y;
+    }
+}
+
+// The scalar end of the train-step loss (util.py:239-250 + stft_loss.py:151-166) in ONE launch instead of four column
+// reductions and ~45 single-element torch kernels: block c reduces one column (the L1 partial sums, then S1, S2, S3 of every
+// resolution) in fp64; the block that arrives last does the algebra
+//   l1 = sum|d| / (B L);  sc_i = sqrt(S1_i) / sqrt(S2_i);  mag_i = S3_i / count_i;
+//   loss = l1 + stft_lambda (lam_sc sum sc_i + lam_mag sum mag_i) / nres
+// and writes the coefficients the backward gather needs (for an upstream gradient of 1; the gather multiplies by it).
+// vals: [0] loss [1] l1 [2] stft_sc * stft_lambda [3] stft_mag * stft_lambda [4] 1 / (B L) [5 + 2i] c_sc_i [6 + 2i] c_mag_i.
+// scratch: 1 + 3 nres doubles + one counter (zero on entry, zero again on exit).
+struct LossDesc {
+    const float* l1_partials; const float* parts[TRUNET_MAX_RES];
+    int n_l1, nres, nrows[TRUNET_MAX_RES]; double l1_count, count[TRUNET_MAX_RES];
+    float sc_lambda, mag_lambda, stft_lambda;
+};
+__global__ __launch_bounds__(1024) void loss_finalize_kernel(const LossDesc d, float* __restrict__ loss_out,
+                                                             float* __restrict__ vals, double* __restrict__ scratch) {
+    __shared__ double red[16];
+    __shared__ int last;
+    const int c = blockIdx.x;                  // column: 0 = L1, 1 + 3 i + j = S_{j+1} of resolution i
+    const float* src; int rows, stride;
+    if (c == 0) { src = d.l1_partials; rows = d.n_l1; stride = 1; }
+    else { const int i = (c - 1) / 3; src = d.parts[i] + (c - 1) % 3; rows = d.nrows[i]; stride = 3; }
+    double s = 0.0;
+    int g = threadIdx.x;
+    for (; g + 3 * 1024 < rows; g += 4 * 1024) {
+        const float v0 = src[(size_t)g * stride], v1 = src[(size_t)(g + 1024) * stride];
+        const float v2 = src[(size_t)(g + 2048) * stride], v3 = src[(size_t)(g + 3072) * stride];
+        s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+    }
+    for (; g < rows; g += 1024) s += (double)src[(size_t)g * stride];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    unsigned int* counter = (unsigned int*)(scratch + 1 + 3 * TRUNET_MAX_RES);
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k];
+        scratch[c] = t;
+        __threadfence();
+        last = (atomicAdd(counter, 1u) == gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!last || threadIdx.x != 0) return;
+    __threadfence();
+    volatile double* sc = scratch;
+    const double l1 = fabs(sc[0] / d.l1_count);
+    double scs = 0.0, mgs = 0.0;
+    for (int i = 0; i < d.nres; ++i) {
+        // the float roundings of the unfused path (reduce_cols stores fp32 sums; torch.sqrt / division in fp32)
+        const float S1 = (float)sc[1 + 3 * i], S2 = (float)sc[2 + 3 * i], S3 = (float)sc[3 + 3 * i];
+        const float r1 = sqrtf(S1), r2 = sqrtf(S2);
+        scs += (double)(r1 / r2);
+        mgs += (double)(S3 / (float)d.count[i]);
+        vals[5 + 2 * i] = d.stft_lambda * d.sc_lambda / (float)d.nres / (r1 * r2);
+        vals[6 + 2 * i] = d.stft_lambda * d.mag_lambda / (float)d.nres / (float)d.count[i];
+    }
+    const float nres = d.nres > 0 ? (float)d.nres : 1.f;
+    const float sc_l = (float)scs * d.sc_lambda / nres * d.stft_lambda, mg_l = (float)mgs * d.mag_lambda / nres * d.stft_lambda;
+    const float loss = (float)l1 + (sc_l + mg_l);
+    loss_out[0] = loss;
+    vals[0] = loss; vals[1] = (float)l1; vals[2] = sc_l; vals[3] = mg_l; vals[4] = (float)(1.0 / d.l1_count);
+    *counter = 0u;
+}
+
+// Gradient of the whole loss with respect to the denoised audio in one gather (no float atomics, deterministic):
+//   g_audio[b][j] = g * ( vals[4] sign(audio - clean) + sum_i ( c_sc_i OLA_i(fr_sc_i)[j] + c_mag_i OLA_i(fr_mag_i)[j] ) )
+// with OLA_i the overlap-add of resolution i's windowed frames over the reflect-padded signal (ola_gather_kernel's index
+// arithmetic), c_* from loss_finalize_kernel and g = the upstream gradient of the loss (device scalar).
+struct GatherDesc {
+    const float* fr_sc[TRUNET_MAX_RES]; const float* fr_mag[TRUNET_MAX_RES];
+    int n[TRUNET_MAX_RES], hop[TRUNET_MAX_RES], wl[TRUNET_MAX_RES], nframes[TRUNET_MAX_RES], nres;
+};
+__global__ __launch_bounds__(256) void loss_grad_gather_kernel(const GatherDesc d, const float* __restrict__ audio,
+                                                               const float* __restrict__ clean,
+                                                               const float* __restrict__ vals, const float* __restrict__ gup,
+                                                               float* __restrict__ g_audio, int L) {
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= L) return;
+    const float df = audio[(size_t)b * L + j] - clean[(size_t)b * L + j];
+    float total = (df > 0.f) ? vals[4] : ((df < 0.f) ? -vals[4] : 0.f);
+    for (int r = 0; r < d.nres; ++r) {
+        const int n = d.n[r], hop = d.hop[r], wl = d.wl[r], nframes = d.nframes[r], left = (n - wl) / 2;
+        const float* fs = d.fr_sc[r] + (size_t)b * nframes * wl;
+        const float* fm = d.fr_mag[r] + (size_t)b * nframes * wl;
+        float as = 0.f, am = 0.f;
+#pragma unroll
+        for (int which = 0; which < 3; ++which) {
+            int v;
+            if (which == 0) v = j;
+            else if (which == 1) { if (j == 0) continue; v = -j; }
+            else { if (j == L - 1) continue; v = 2 * (L - 1) - j; }
+            const int hi = v + n / 2 - left;
+            const int lo = v + n / 2 - left - wl + 1;
+            if (hi < 0) continue;
+            int f0 = lo <= 0 ? 0 : (lo + hop - 1) / hop;
+            int f1 = hi / hop;
+            if (f1 > nframes - 1) f1 = nframes - 1;
+            for (int f = f0; f <= f1; ++f) {
+                const size_t o = (size_t)f * wl + (v - f * hop + n / 2 - left);
+                as += fs[o];
+                am += fm[o];
+            }
+        }
+        total = fmaf(vals[5 + 2 * r], as, fmaf(vals[6 + 2 * r], am, total));
+    }
+    g_audio[(size_t)b * L + j] = gup[0] * total;
+}
+
 // stft() of stft_loss.py:9-30 for two signals at once: magnitudes sqrt(clamp(re^2 + im^2, 1e-7)) as (B, frames, bins)
 template <int NI>
 __global__ __launch_bounds__(256) void stft_mag_kernel(const float* __restrict__ x, const float* __restrict__ y,
@@ -728,6 +909,56 @@ extern "C" int trunet_stft_loss_bwd_gather(const float* x, const float* y, const
 #undef BWD_
     hipLaunchKernelGGL(ola_gather_kernel, dim3((L + 255) / 256, B), dim3(256), 0, ST, frames, gx, L, n, hop, nframes,
                        win_length, left);
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_stft_loss_fwdgrad(const float* x, const float* y, const float* win, const float* tw, float* partials,
+                                        float* fr_sc, float* fr_mag, int B, int L, int n, int hop, int win_length, void* stream) {
+    const int logn = ilog2(n);
+    if (!x || !y || !win || !tw || !partials || !fr_sc || !fr_mag || B <= 0 || logn < 3 || n > 4096 || hop <= 0 || L <= n / 2 ||
+        win_length <= 0 || win_length > n)
+        return TRUNET_EINVAL;
+    const int nframes = 1 + L / hop;
+    const int left = (n - win_length) / 2;
+#define FG_(NI_) hipLaunchKernelGGL(stft_loss_fwdgrad_kernel<NI_>, dim3(nframes, B), dim3(256), (2 * n + n / 2) * sizeof(cpx), ST, x, y, \
+                                   win, (const cpx*)tw, partials, fr_sc, fr_mag, L, n, logn, hop, nframes, win_length, left)
+    if (n == 512) FG_(2); else if (n == 1024) FG_(4); else if (n == 2048) FG_(8); else FG_(0);
+#undef FG_
+    return trunet_launch_status();
+}
+
+extern "C" size_t trunet_loss_scratch_bytes(void) { return (1 + 3 * TRUNET_MAX_RES + 1) * sizeof(double); }
+
+extern "C" int trunet_loss_finalize(const trunet_loss_args* a, float* loss_out, float* vals, void* scratch, void* stream) {
+    if (!a || !loss_out || !vals || !scratch || !a->l1_partials || a->n_l1 <= 0 || a->l1_count <= 0 || a->nres < 0 ||
+        a->nres > TRUNET_MAX_RES)
+        return TRUNET_EINVAL;
+    LossDesc d;
+    d.l1_partials = a->l1_partials; d.n_l1 = a->n_l1; d.nres = a->nres; d.l1_count = a->l1_count;
+    d.sc_lambda = a->sc_lambda; d.mag_lambda = a->mag_lambda; d.stft_lambda = a->stft_lambda;
+    for (int i = 0; i < a->nres; ++i) {
+        if (!a->parts[i] || a->nrows[i] <= 0 || a->count[i] <= 0) return TRUNET_EINVAL;
+        d.parts[i] = a->parts[i]; d.nrows[i] = a->nrows[i]; d.count[i] = a->count[i];
+    }
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1 + 3 * a->nres), dim3(1024), 0, ST, d, loss_out, vals, (double*)scratch);
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_loss_grad_gather(const trunet_loss_gather_args* a, const float* audio, const float* clean,
+                                       const float* vals, const float* g_loss, float* g_audio, int B, int L, void* stream) {
+    if (!a || !audio || !clean || !vals || !g_loss || !g_audio || B <= 0 || L <= 0 || a->nres < 0 || a->nres > TRUNET_MAX_RES)
+        return TRUNET_EINVAL;
+    GatherDesc d;
+    d.nres = a->nres;
+    for (int i = 0; i < a->nres; ++i) {
+        if (!a->fr_sc[i] || !a->fr_mag[i] || ilog2(a->n[i]) < 3 || a->hop[i] <= 0 || a->win_length[i] <= 0 ||
+            a->win_length[i] > a->n[i] || L <= a->n[i] / 2)
+            return TRUNET_EINVAL;
+        d.fr_sc[i] = a->fr_sc[i]; d.fr_mag[i] = a->fr_mag[i]; d.n[i] = a->n[i]; d.hop[i] = a->hop[i];
+        d.wl[i] = a->win_length[i]; d.nframes[i] = 1 + L / a->hop[i];
+    }
+    hipLaunchKernelGGL(loss_grad_gather_kernel, dim3((L + 255) / 256, B), dim3(256), 0, ST, d, audio, clean, vals, g_loss,
+                       g_audio, L);
     return trunet_launch_status();
 }
 

@@ -640,7 +640,7 @@ extern "C" int trunet_conv_gemm(const trunet_gemm_args* h, void* stream) {
     GemmPlan pl;
     if (plan_gemm(h, &pl) != TRUNET_OK) return TRUNET_ENOTSUP;
     hipStream_t st = (hipStream_t)stream;
-    if (h->epi & TRUNET_EPI_STATS) {
+    if ((h->epi & TRUNET_EPI_STATS) && !(h->epi & TRUNET_EPI_PREZERO)) {
         // statistics rows are indexed by (blockIdx.x*CG + cg); rows of unused parts must read as zero
         size_t bytes = (size_t)trunet_conv_gemm_nparts(h->M) * h->M_stat * 2 * sizeof(float);
         if (hipMemsetAsync(h->partials, 0, bytes, st) != hipSuccess) return TRUNET_ELAUNCH;

@@ -814,7 +814,7 @@ extern "C" int trunet_pw_bwd(const trunet_pwbwd_args* H, void* stream) {
             if (sg.mode == TRUNET_PRO_BNRELU && (!sg.c0 || !sg.c1)) return TRUNET_EINVAL;
             if (!(dg.flags & TRUNET_DG_STORE) || !dg.out) return TRUNET_ENOTSUP;
             if ((dg.flags & TRUNET_DG_STATS) && (!(dg.flags & TRUNET_DG_MASK) || !dg.partials || !dg.e2)) return TRUNET_EINVAL;
-            if (dg.flags & TRUNET_DG_STATS) {
+            if ((dg.flags & TRUNET_DG_STATS) && !(dg.flags & TRUNET_DG_PREZERO)) {
                 const size_t bytes = (size_t)trunet_pw_bwd_nparts() * sg.nchan * 2 * sizeof(float);
                 if (hipMemsetAsync(dg.partials, 0, bytes, st) != hipSuccess) return TRUNET_ELAUNCH;
             }
@@ -887,17 +887,19 @@ extern "C" int trunet_pw_bwd(const trunet_pwbwd_args* H, void* stream) {
     const size_t lds = fixed + NB * slot;
     for (int s = 0; s < h->nseg; ++s) {
         const trunet_dgrad_out& dg = H->dg[s];
-        if (dg.flags & TRUNET_DG_STATS) {
+        if ((dg.flags & TRUNET_DG_STATS) && !(dg.flags & TRUNET_DG_PREZERO)) {
             const size_t bytes = (size_t)PWB_GRID * PWB_SHARE * h->seg[s].nchan * 2 * sizeof(float);
             if (hipMemsetAsync(dg.partials, 0, bytes, st) != hipSuccess) return TRUNET_ELAUNCH;
         }
     }
+    trunet_pwbwd_args HK = *H;          // the kernel compares the per-segment flags exactly: host-only bits stay on the host
+    for (int s = 0; s < TRUNET_MAX_SEG; ++s) HK.dg[s].flags &= ~TRUNET_DG_PREZERO;
 #define PWB_LAUNCH(AK_, SEC_, KS_)                                                                                     \
     do {                                                                                                               \
         auto kern = pw_bwd_kernel<AK_, SEC_, KS_>;                                                                        \
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
             return TRUNET_ELAUNCH;                                                                                     \
-        hipLaunchKernelGGL(kern, dim3(PWB_GRID), dim3(512), lds, st, *H, sch, NB, rows);                               \
+        hipLaunchKernelGGL(kern, dim3(PWB_GRID), dim3(512), lds, st, HK, sch, NB, rows);                               \
     } while (0)
     if (MA == 32) PWB_LAUNCH(16, false, false);
     else if (MA == 64 && sec) PWB_LAUNCH(32, true, false);

@@ -15,7 +15,7 @@ import torch
 from . import _lib as L
 import os
 
-from ._lib import (DG_ACCUM, DG_MASK, DG_STATS, DG_STORE, EPI_ACCUM, EPI_BIAS, EPI_MASK, EPI_STATS, PRO_BNBWD,
+from ._lib import (DG_ACCUM, DG_MASK, DG_PREZERO, DG_STATS, DG_STORE, EPI_ACCUM, EPI_BIAS, EPI_MASK, EPI_PREZERO, EPI_STATS, PRO_BNBWD,
                    PRO_BNRELU, PRO_NONE, ConvtBwdArgs, GemmArgs, PwBwdArgs, WgradArgs, check, make_seg, ptr)
 
 F_BINS = 257
@@ -137,6 +137,17 @@ class Workspace:
         self.dev = dev
         self.t = {}
         self.gen = 0
+        # statistics partial buffers that a producer has written and no trunet_bn_finalize_* has consumed yet.  The finalize
+        # kernels leave the rows they read ZERO, so a buffer that is not pending is all zero (flat(zero=True) at birth) and
+        # its next producer can skip its zero-fill launch (TRUNET_EPI_PREZERO / TRUNET_DG_PREZERO: 46 launches per step);
+        # after an exception between a producer and its finalize the name stays pending and the producer zero-fills again.
+        self.pending = set()
+
+    def take_clean(self, name):
+        """True when partial buffer `name` is known to be all zero; either way it is marked as written"""
+        clean = name not in self.pending
+        self.pending.add(name)
+        return clean
 
     def get(self, name, shape, zero=False, dtype=torch.float32):
         t = self.t.get(name)
@@ -154,7 +165,20 @@ class Workspace:
         if t is None or t.numel() < numel:
             t = (torch.zeros if zero else torch.empty)(max(numel, 1), device=self.dev, dtype=dtype)
             self.t[name] = t
+            self.pending.discard(name)
         return t
+
+    def zero_crop(self, t, q0, q1):
+        """Positions [0, q0) and [q1, L) of gradient tensor t [C][L][...] are never written by any kernel (the cropped
+        positions of network.py:96-97) and must read as zero: zero-filled once per tensor object, not once per step."""
+        key = "crop0:%d" % id(t)
+        if self.t.get(key) is not None and self.t[key][0] is t and self.t[key][1:] == (q0, q1):
+            return
+        if q0 > 0:
+            t[:, :q0].zero_()
+        if q1 < t.shape[1]:
+            t[:, q1:].zero_()
+        self.t[key] = (t, q0, q1)
 
     def bn(self, name, C):
         b = self.t.get("bn:" + name)
@@ -212,8 +236,10 @@ class TRUNetEngine:
         if stats is not None:
             epi |= EPI_STATS
             nparts = L.lib().trunet_conv_gemm_nparts(M)
-            part = w.flat("partials", nparts * stats * 2)
+            part = w.flat("partials", nparts * stats * 2, zero=True)
             a.partials, a.M_stat = ptr(part), stats
+            if w.take_clean("partials"):
+                epi |= EPI_PREZERO
         a.epi = epi
         if PROFILE is not None:
             fl = 2.0 * N * M * sum(s.nchan * _seg_positions(s, p_begin, P) for s in segs)
@@ -374,7 +400,7 @@ class TRUNetEngine:
         st.module, st.count = module, float(count)
         lib = L.lib()
         if training:
-            part = w.flat("partials", nparts * C * 2)
+            part = w.flat("partials", nparts * C * 2, zero=True)
             L.bump_mutation_epoch()     # running statistics are written through raw pointers
             rm = module.running_mean if module.track_running_stats else None
             rv = module.running_var if module.track_running_stats else None
@@ -384,6 +410,7 @@ class TRUNetEngine:
                                              ptr(module.bias.data), module.eps, mom, ptr(rm), ptr(rv),
                                              ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.rstd), nbt, L.stream()),
                   "bn_finalize_fwd")
+            w.pending.discard("partials")
         else:
             check(lib.trunet_bn_eval_affine(C, ptr(module.weight.data), ptr(module.bias.data),
                                             ptr(module.running_mean), ptr(module.running_var), module.eps,
@@ -722,11 +749,12 @@ class TRUNetEngine:
     # ------------------------------------------------------------------ backward
     def _bn_bwd(self, w, st, nparts, grads, part_name="partials"):
         m = st.module
-        part = w.flat(part_name, nparts * st.C * 2)
+        part = w.flat(part_name, nparts * st.C * 2, zero=True)
         # dgamma / dbeta go straight into the parameters' slots of partial image 0 (the other images hold zeros there)
         check(L.lib().trunet_bn_finalize_bwd(ptr(part), nparts, st.C, st.count, ptr(m.weight.data), ptr(st.mean),
                                              ptr(st.rstd), self._wg_slot(m.weight), self._wg_slot(m.bias), ptr(st.ca),
                                              ptr(st.cb), ptr(st.cc), L.stream()), "bn_finalize_bwd")
+        w.pending.discard(part_name)
 
     # ---- gradient partial images: every parameter owns a slice of ONE buffer [nparts][total] (slices start at multiples
     # of 64 elements).  The conv / GRU weight-gradient launches write their per-workgroup partial images straight into
@@ -835,9 +863,11 @@ class TRUNetEngine:
                     d.zmask = ptr(src.t)
                     if src.bn is not None:
                         fl |= DG_STATS
-                        part = w.flat("pwb_partials%d" % i, nparts * sg.nchan * 2)
+                        part = w.flat("pwb_partials%d" % i, nparts * sg.nchan * 2, zero=True)
                         d.e2, d.partials = ptr(src.bn.mean), ptr(part)
                         stat_parts.append((src.bn, "pwb_partials%d" % i))
+                        if w.take_clean("pwb_partials%d" % i):
+                            fl |= DG_PREZERO
                 if o.get("accum"):
                     fl |= DG_ACCUM
                 d.flags = fl
@@ -855,6 +885,8 @@ class TRUNetEngine:
                 for bn, pname in stat_parts:
                     self._bn_bwd(w, bn, nparts, grads, part_name=pname)
                 return
+            for _, pname in stat_parts:          # nothing was launched: the statistics buffers are as clean as before
+                w.pending.discard(pname)
             if rc != L.TRUNET_ENOTSUP or must_fuse:
                 check(rc, "pw_bwd")
         assert not (a_m_off or w_m_off or b_off), "row blocks exist on the fused kernel only"
@@ -909,11 +941,7 @@ class TRUNetEngine:
         srcs = [x1.seg(pos_off=-left, woff=0)] + ([skip.seg(woff=x1.C)] if skip is not None else [])
         p0, p1 = max(0, left), min(Lp, x1.L + left)
         if p1 - p0 < x1.L:          # cropped positions of x1 (network.py:96-97 with a negative pad) get no gradient
-            q0, q1 = p0 - left, p1 - left
-            if q0 > 0:
-                dy_x1[:, :q0].zero_()
-            if q1 < x1.L:
-                dy_x1[:, q1:].zero_()
+            w.zero_crop(dy_x1, p0 - left, p1 - left)
         outs = [dict(out=dy_x1, src=x1_mask)] + ([dict(out=g_skip)] if skip is not None else [])
         # decoder.5's 8-row layer: trunet_pw_bwd pads its dz block to one 32-row MFMA tile (round 3; TRUNET_FUSED_THIN=0
         # keeps the three separate launches of rounds 1-2: conv_wgrad + two conv_gemm, 1.36 ms)

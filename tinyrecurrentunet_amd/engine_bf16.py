@@ -19,7 +19,7 @@ from . import _lib as L
 from . import engine as E
 import os
 
-from ._lib import (DG_ACCUM, DG_MASK, DG_STATS, DG_STORE, EPI_ACCUM, EPI_BIAS, EPI_F32OUT, EPI_MASK, EPI_RELU, EPI_STATS, PRO_BNBWD,
+from ._lib import (DG_ACCUM, DG_MASK, DG_PREZERO, DG_STATS, DG_STORE, EPI_ACCUM, EPI_BIAS, EPI_F32OUT, EPI_MASK, EPI_PREZERO, EPI_RELU, EPI_STATS, PRO_BNBWD,
                    PRO_BNRELU, PRO_NONE, BConvtArgs, BGemmArgs, BPackDesc, BPwBwdArgs, BSeg, BWgradArgs, check, ptr, ptr16)
 from .engine import BN_MOM, F_BINS, FRAME_PAD, Act, TRUNetEngine, _Timed, _seg_positions, ceil_to
 
@@ -106,12 +106,36 @@ class TRUNetEngineBF16(TRUNetEngine):
     """TRUNetEngine with bf16 activation storage (see the module docstring)."""
 
     # ------------------------------------------------------------------ packed weight images
-    def _pack(self, W, M, ldw_m, ldw_c, w_m_off, nchan, woff):
+    def _pack_group(self, specs):
+        """Several images back to back in the pool (the W^T row tiles of a pointwise layer with more than 128 source
+        channels: one image per source, read by the kernel as ONE image): specs = [(W, M, ldw_m, ldw_c, w_m_off, nchan,
+        woff), ...]; returns the address of the first.  The members are ordinary plan entries (tagged, so they are never
+        shared with a stand-alone image of the same weight), allocated consecutively the first time and refreshed by the
+        batched pack launch afterwards -- until round 4 these were packed by their own launches in every step."""
+        plan = self.__dict__.setdefault("_pk", {})
+        keys = [(W.data_ptr(), M, ldw_m, ldw_c, w_m_off, tuple(nchan), tuple(woff), "grp%d/%d" % (i, len(specs)))
+                for i, (W, M, ldw_m, ldw_c, w_m_off, nchan, woff) in enumerate(specs)]
+        have = [k in plan for k in keys]
+        if any(have) and not all(have):             # a partly aged-out group: re-allocate all of it
+            for k in keys:
+                plan.pop(k, None)
+            self._pkdirty = True
+        if not all(have) and self.__dict__.get("_pkbuf") is not None:
+            need = sum(((M + 31) // 32) * sum(_ksteps(c) for c in nchan) * 64 * 8 for (_, M, _, _, _, nchan, _) in specs)
+            if self._pkoff + need > PACK_POOL_ELEMS:
+                plan.clear()
+                self._pkoff = 0
+        ptrs = [self._pack(*sp, tag=k[-1]) for sp, k in zip(specs, keys)]
+        for (W, M, ldw_m, ldw_c, w_m_off, nchan, woff), p0, p1 in zip(specs, ptrs, ptrs[1:]):
+            assert p1 - p0 == 2 * ((M + 31) // 32) * sum(_ksteps(c) for c in nchan) * 64 * 8, "group images are not contiguous"
+        return ptrs[0]
+
+    def _pack(self, W, M, ldw_m, ldw_c, w_m_off, nchan, woff, tag=None):
         """Device address of the MFMA A-fragment image of (W, addressing): taken from this step's batch when the plan
         knows it, else packed now (and added to the plan)."""
         lib, st = L.lib(), L.stream()
         nks = sum(_ksteps(c) for c in nchan)
-        key = (W.data_ptr(), M, ldw_m, ldw_c, w_m_off, tuple(nchan), tuple(woff))
+        key = (W.data_ptr(), M, ldw_m, ldw_c, w_m_off, tuple(nchan), tuple(woff)) + ((tag,) if tag else ())
         plan = self.__dict__.setdefault("_pk", {})
         if self.__dict__.get("_pkbuf") is None or self._pkbuf.device != W.device:
             self._pkbuf = torch.empty(PACK_POOL_ELEMS, device=W.device, dtype=BF16)
@@ -207,9 +231,9 @@ class TRUNetEngineBF16(TRUNetEngine):
         if stats is not None:
             epi |= EPI_STATS
             nparts = lib.trunet_bf16_gemm_nparts()
-            part = w.flat("partials", nparts * stats * 2)
+            part = w.flat("partials", nparts * stats * 2, zero=True)
             a.partials, a.M_stat = ptr(part), stats
-        a.epi = epi
+        a.epi = epi | (EPI_PREZERO if (stats is not None and w.take_clean("partials")) else 0)
         if E.PROFILE is not None:
             # algorithmic bytes: every valid source row read once (twice for a BatchNorm-backward pair), the output row
             # written once (+ read for accumulate / mask), 2 bytes per element over the N valid frames
@@ -539,19 +563,10 @@ class TRUNetEngineBF16(TRUNetEngine):
         # W^T of all sources as ONE image: A(c, m) = W[m*K + c] for c over the concatenated source channels (the sources'
         # woff are consecutive: woff_s = channels before s), i.e. row tiles of the sources one after the other
         assert [s.woff for s in segs] == [sum(t.nchan for t in segs[:i]) for i in range(len(segs))]
-        wfragT_ptr = self._pack(W.data, K, 1, K, 0, [M], [0]) if K <= 128 else None
-        if wfragT_ptr is None:       # more than 128 rows: two images back to back are not one pool entry: pack per source
-            wfragT = w.flat("wfragT", nrt_total * nks * 64 * 8, dtype=BF16)
-            one = (C.c_int32 * 1)(M)
-            zero = (C.c_int32 * 1)(0)
-            rt0 = 0
-            for s in segs:
-                rc = lib.trunet_bf16_pack_weight(ptr(W.data), wfragT.data_ptr() + rt0 * nks * 64 * 16, s.nchan, 1, K, s.woff, 1,
-                                                 one, zero, st)
-                if rc != nks:
-                    raise L.TrunetHipError("trunet_bf16_pack_weight (W^T): code %d" % rc)
-                rt0 += s.nchan // 32
-            wfragT_ptr = wfragT.data_ptr()
+        if K <= 128:
+            wfragT_ptr = self._pack(W.data, K, 1, K, 0, [M], [0])
+        else:       # more than 128 rows (the pack kernel's limit per image): one image per source, back to back in the pool
+            wfragT_ptr = self._pack_group([(W.data, s.nchan, 1, K, s.woff, [M], [0]) for s in segs])
         a = BPwBwdArgs()
         aw = a.w
         aw.NP, aw.N, aw.P, aw.p_begin = NP, N, P, 0
@@ -574,9 +589,11 @@ class TRUNetEngineBF16(TRUNetEngine):
                 fl |= DG_MASK
                 if src.bn is not None:
                     fl |= DG_STATS
-                    part = w.flat("pwb16_partials%d" % i, nparts * sg.nchan * 2)
+                    part = w.flat("pwb16_partials%d" % i, nparts * sg.nchan * 2, zero=True)
                     a.dg.mean[i], a.dg.partials[i] = ptr(src.bn.mean), ptr(part)
                     stat_parts.append((src.bn, "pwb16_partials%d" % i))
+                    if w.take_clean("pwb16_partials%d" % i):
+                        fl |= DG_PREZERO
             if o.get("accum"):
                 fl |= DG_ACCUM
             a.dg.flags[i] = fl
@@ -591,6 +608,8 @@ class TRUNetEngineBF16(TRUNetEngine):
         else:
             rc = lib.trunet_bf16_pw_bwd(a, st)
         if rc == L.TRUNET_ENOTSUP:
+            for _, pname in stat_parts:          # nothing was launched: the statistics buffers are as clean as before
+                w.pending.discard(pname)
             return False
         check(rc, "bf16_pw_bwd")
         for bn, pname in stat_parts:
@@ -612,8 +631,9 @@ class TRUNetEngineBF16(TRUNetEngine):
         a.ca, a.cb, a.cc = ptr(bn.ca), ptr(bn.cb), ptr(bn.cc)
         a.src, a.s_scale, a.s_shift, a.s_mean = ptr16(a_pw.t), ptr(a_pw.bn.scale), ptr(a_pw.bn.shift), ptr(a_pw.bn.mean)
         nparts = lib.trunet_bf16_convt_bwd_nparts()
-        part = w.flat("ct16_partials", nparts * Ci * 2)
+        part = w.flat("ct16_partials", nparts * Ci * 2, zero=True)
         a.wfragT, a.dsrc, a.partials = wfragT_ptr, ptr16(dy_pw), ptr(part)
+        a.prezero = 1 if w.take_clean("ct16_partials") else 0
         a.w_numel = self._wg_total
         a.w_partials, a.b_partials = self._wg_slot(ct.weight), self._wg_slot(ct.bias)
         a.b_stride, a.b_off = self._wg_total, 0
@@ -624,6 +644,7 @@ class TRUNetEngineBF16(TRUNetEngine):
         else:
             rc = lib.trunet_bf16_convt_bwd(a, st)
         if rc == L.TRUNET_ENOTSUP:
+            w.pending.discard("ct16_partials")
             return False
         check(rc, "bf16_convt_bwd")
         self._bn_bwd(w, a_pw.bn, nparts, grads, part_name="ct16_partials")
@@ -661,11 +682,7 @@ class TRUNetEngineBF16(TRUNetEngine):
         srcs = [x1.seg(pos_off=-left, woff=0)] + ([skip.seg(woff=x1.C)] if skip is not None else [])
         p0, p1 = max(0, left), min(Lp, x1.L + left)
         if p1 - p0 < x1.L:          # cropped positions of x1 (network.py:96-97 with a negative pad) get no gradient
-            q0, q1 = p0 - left, p1 - left
-            if q0 > 0:
-                dy_x1[:, :q0].zero_()
-            if q1 < x1.L:
-                dy_x1[:, q1:].zero_()
+            w.zero_crop(dy_x1, p0 - left, p1 - left)
         outs = [dict(out=dy_x1, src=x1_mask)] + ([dict(out=g_skip)] if skip is not None else [])
         self._pw_bwd16(w, N=N, NP=NP, P=Lp, M=pw.out_channels, dz=dy_pw, dz1=a_pw.t, dz_bn=a_pw.bn, W=pw.weight,
                        bias=pw.bias, segs=srcs, outs=outs, grads=grads)
