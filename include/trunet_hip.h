@@ -333,6 +333,19 @@ int trunet_stft_loss_fwd(const float* x, const float* y, const float* win, const
  * the window's support, centred in n) and a gather sums them per sample; gx is written (not accumulated), deterministic. */
 int trunet_stft_loss_bwd_gather(const float* x, const float* y, const float* win, const float* tw, const float* coef,
                                 float* frames, float* gx, int B, int L, int n, int hop, int win_length, void* stream);
+/* ---- causal audio-in -> audio-out stream (stream.py:83-109: ProcessAudio + model per chunk), S concurrent streams, one hop
+ * of 128 samples per stream and call; all state lives in caller-owned device tensors with fixed addresses (hipGraph-replayable).
+ * trunet_stream_features: ring (S, 512) <- [ring[:, 128:], chunk (S, 128)] (chunk NULL: the ring already holds the frame, used
+ * for the reflect-padded first frame of dataset.py:260-264), then ONE frame of ProcessAudio.forward (dataset.py:246-272) per
+ * stream -> feat (S, C, 257); C = 4: PCEN (dataset.py:56-76) with the smoother carried in pcen_M (S, 257) (first != 0: M = s x). */
+int trunet_stream_features(float* ring, const float* chunk, float* pcen_M, float* feat, const float* tw512, int S, int C,
+                           int first, float eps, float s, float alpha, float delta, float r, void* stream);
+/* trunet_stream_mask_istft: net output of one frame per stream (S, 8, 257) -> phase-aware mask (phm.py:31-45) -> irFFT-512
+ * (dataset.py:182-203) -> overlap-add into ola (S, 512) -> out (S, 128) = the hop that is final now / env (number of frames
+ * covering it, dataset.py:293-296: torch.istft's window envelope for the rectangular window); ola shifted by one hop. */
+int trunet_stream_mask_istft(const float* net_out, float* ola, float* out, const float* tw512, int S, float beta, float env,
+                             void* stream);
+
 /* ---- the train step's loss as util.loss_fn composes it (util.py:239-250, stft_loss.py:141-166), fused (round 4) ----
  * trunet_stft_loss_fwdgrad: trunet_stft_loss_fwd's three sums per frame AND the two coefficient-free gradient frames of the
  * same resolution (fr_sc, fr_mag: (B, frames, win_length)) from one pass: the gradient of a resolution is

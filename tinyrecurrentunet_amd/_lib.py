@@ -191,6 +191,8 @@ def _declare(L):
         "trunet_stft_loss_fwd": [p, p, p, p, p, i, i, i, i, p],
         "trunet_stft_mag": [p, p, p, p, p, p, i, i, i, i, p],
         "trunet_stft_loss_fwdgrad": [p, p, p, p, p, p, p, i, i, i, i, i, p],
+        "trunet_stream_features": [p, p, p, p, p, i, i, i, f, f, f, f, f, p],
+        "trunet_stream_mask_istft": [p, p, p, p, i, f, f, p],
         "trunet_loss_scratch_bytes": [],
         "trunet_loss_finalize": [C.POINTER(LossArgs), p, p, p, p],
         "trunet_loss_grad_gather": [C.POINTER(LossGatherArgs), p, p, p, p, p, i, i, p],

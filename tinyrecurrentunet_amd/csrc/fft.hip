@@ -395,6 +395,111 @@ __global__ __launch_bounds__(256) void mask_istft_bwd_kernel(const float* __rest
     }
 }
 
+// ---------------------------------------------------------------- causal audio-in -> audio-out stream (stream.py:83-109)
+// One new hop of 128 samples per stream and call.  State per stream: the last 512 input samples (`ring`), the PCEN
+// smoother M (dataset.py:56-76: M[t] = (1-s) M[t-1] + s x[t], M[0] = s x[0]) and the overlap-add tail of the output.
+// stream_features_kernel: ring <- [ring[128:], chunk] (chunk == NULL: the ring already holds the frame), rect-window
+// rFFT-512 of the ring = ONE STFT frame of dataset.py:246-272 (the frame the centred STFT produces two hops later), the same
+// arithmetic per bin as stft_features_kernel / pcen_*_kernel, PCEN with the carried state.  Block = two streams (two real
+// frames share one complex FFT); feat: (S, C, 257).
+__global__ __launch_bounds__(256) void stream_features_kernel(float* __restrict__ ring, const float* __restrict__ chunk,
+                                                              float* __restrict__ pcen_M, float* __restrict__ feat,
+                                                              const cpx* __restrict__ tw, int S, int C, int first, float eps,
+                                                              float s, float alpha, float delta, float r, float dr) {
+    __shared__ cpx sa[NF], sb[NF];
+    const int s0 = blockIdx.x * 2;
+    const bool two = s0 + 1 < S;
+    for (int i = threadIdx.x; i < NF; i += 256) {
+        float v[2] = {0.f, 0.f};
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            if (f == 1 && !two) continue;
+            float* rg = ring + (size_t)(s0 + f) * NF;
+            if (chunk) v[f] = (i < NF - HOPF) ? rg[i + HOPF] : chunk[(size_t)(s0 + f) * HOPF + (i - (NF - HOPF))];
+            else v[f] = rg[i];
+        }
+        sa[i] = make_float2(v[0], v[1]);
+    }
+    __syncthreads();                      // every old ring sample has been read before the shifted ring is written
+    if (chunk) {
+        for (int i = threadIdx.x; i < NF; i += 256) {
+            ring[(size_t)s0 * NF + i] = sa[i].x;
+            if (two) ring[(size_t)(s0 + 1) * NF + i] = sa[i].y;
+        }
+    }
+    const cpx* Z = fft_lds_t<9, false>(sa, sb, tw);
+    for (int k = threadIdx.x; k < BINS; k += 256) {
+        cpx X[2];
+        split_pair(Z, k, NF, X[0], X[1]);
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            if (f == 1 && !two) continue;
+            const float re = X[f].x, im = X[f].y;
+            const float mag = sqrtf(re * re + im * im);
+            const float db = 20.f * log10f(fmaxf(mag, 1e-7f)) - 25.f;
+            float nm = ((db + 100.f) / 100.f) * 2.f - 1.f;
+            nm = fminf(fmaxf(nm, -1.f), 1.f);
+            float sn = 0.f, cs = 1.f;
+            if (mag > 0.f) { sn = im / mag; cs = re / mag; }
+            float* o = feat + ((size_t)(s0 + f) * C) * BINS + k;
+            o[0] = nm;
+            o[(size_t)(C - 2) * BINS] = sn;
+            o[(size_t)(C - 1) * BINS] = cs;
+            if (C == 4) {
+                float* Mp = pcen_M + (size_t)(s0 + f) * BINS + k;
+                const float M = first ? s * mag : (1.f - s) * (*Mp) + s * mag;
+                *Mp = M;
+                o[BINS] = powf(mag / powf(M + eps, alpha) + delta, r) - dr;
+            }
+        }
+    }
+}
+
+// stream_mask_istft_kernel: net output of ONE frame per stream (S, 8, 257) -> phase-aware mask -> irFFT-512 (the arithmetic
+// of mask_istft_frames_kernel) -> overlap-add into the stream's tail `ola` (512 partial sums of the padded positions
+// [128 t, 128 t + 512), frames added in ascending order like ola_kernel) -> the 128 samples that are final now, divided by
+// the number of frames that cover them (`env`: 4 in steady state, fewer at the ends of an utterance) -> tail shifted by a hop.
+__global__ __launch_bounds__(256) void stream_mask_istft_kernel(const float* __restrict__ net_out, float* __restrict__ ola,
+                                                                float* __restrict__ out, const cpx* __restrict__ tw, int S,
+                                                                float beta, float env) {
+    __shared__ cpx sa[NF], sb[NF];
+    const int s0 = blockIdx.x * 2;
+    const bool two = s0 + 1 < S;
+    for (int k = threadIdx.x; k < BINS; k += 256) {
+        cpx X[2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            X[f] = make_float2(0.f, 0.f);
+            if (f == 0 || two) {
+                const MaskVals v = mask_vals(net_out + (size_t)(s0 + f) * 8 * BINS + k, BINS, beta);
+                const float M = v.S * v.A;
+                X[f] = make_float2(M * v.cm, M * v.sm);
+            }
+            if (k == 0 || k == NF / 2) X[f].y = 0.f;
+        }
+        sa[k] = make_float2(X[0].x - X[1].y, X[0].y + X[1].x);
+        if (k > 0 && k < NF / 2) sa[NF - k] = make_float2(X[0].x + X[1].y, -X[0].y + X[1].x);
+    }
+    const cpx* z = fft_lds_t<9, true>(sa, sb, tw);
+    cpx* acc = (z == sa) ? sb : sa;       // the other buffer: free after the transform
+    for (int i = threadIdx.x; i < NF; i += 256) {
+        const cpx v = z[i];
+        float a0 = ola[(size_t)s0 * NF + i] + v.x * (1.f / NF);
+        float a1 = two ? ola[(size_t)(s0 + 1) * NF + i] + v.y * (1.f / NF) : 0.f;
+        acc[i] = make_float2(a0, a1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NF; i += 256) {
+        const cpx nx = (i + HOPF < NF) ? acc[i + HOPF] : make_float2(0.f, 0.f);
+        ola[(size_t)s0 * NF + i] = nx.x;
+        if (two) ola[(size_t)(s0 + 1) * NF + i] = nx.y;
+        if (i < HOPF) {
+            out[(size_t)s0 * HOPF + i] = acc[i].x / env;
+            if (two) out[(size_t)(s0 + 1) * HOPF + i] = acc[i].y / env;
+        }
+    }
+}
+
 // One windowed frame pair z = w x + j w y into LDS, and the n/2 twiddles next to it.  NI = n / 256 is a COMPILE-TIME
 // count (2 / 4 / 8 for the three resolutions of config/tiny.json), so that a thread's NI (reflected) samples of both
 // signals are requested before the first one is used: as a `for (i = tid; i < n; i += 256)` loop of unknown trip count
@@ -909,6 +1014,22 @@ extern "C" int trunet_stft_loss_bwd_gather(const float* x, const float* y, const
 #undef BWD_
     hipLaunchKernelGGL(ola_gather_kernel, dim3((L + 255) / 256, B), dim3(256), 0, ST, frames, gx, L, n, hop, nframes,
                        win_length, left);
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_stream_features(float* ring, const float* chunk, float* pcen_M, float* feat, const float* tw512, int S,
+                                      int C, int first, float eps, float s, float alpha, float delta, float r, void* stream) {
+    if (!ring || !feat || !tw512 || S <= 0 || (C != 3 && C != 4) || (C == 4 && !pcen_M)) return TRUNET_EINVAL;
+    hipLaunchKernelGGL(stream_features_kernel, dim3((S + 1) / 2), dim3(256), 0, ST, ring, chunk, pcen_M, feat, (const cpx*)tw512,
+                       S, C, first, eps, s, alpha, delta, r, powf(delta, r));
+    return trunet_launch_status();
+}
+
+extern "C" int trunet_stream_mask_istft(const float* net_out, float* ola, float* out, const float* tw512, int S, float beta,
+                                        float env, void* stream) {
+    if (!net_out || !ola || !out || !tw512 || S <= 0 || !(env >= 1.f)) return TRUNET_EINVAL;
+    hipLaunchKernelGGL(stream_mask_istft_kernel, dim3((S + 1) / 2), dim3(256), 0, ST, net_out, ola, out, (const cpx*)tw512, S,
+                       beta, env);
     return trunet_launch_status();
 }
 

@@ -268,6 +268,17 @@ class TRUNet(nn.Module):
             out, _ = self._engine.forward(x.float(), False, tgru_state=state)
         return out, state
 
+    def stream_audio(self, chunk, state=None, tgru=None):
+        """Causal audio-in -> audio-out step (stream.py:83-109): ``chunk`` (streams, 128) new samples per stream ->
+        (denoised samples that became final, state).  ``state`` is a ``streaming.AudioStream`` (created on the first call:
+        analysis ring, PCEN smoother, overlap-add tail and -- ``tgru`` / ``use_tgru`` -- the TGRU hidden state); call
+        ``state.flush()`` at the end of the utterance.  Three launches per hop; see streaming.py for the latency contract."""
+        _need_gpu(chunk)
+        if state is None:
+            from .streaming import AudioStream
+            state = AudioStream(self, chunk.shape[0], tgru=self.use_tgru if tgru is None else tgru)
+        return state.push(chunk), state
+
     def _active_params(self):
         return [p for n, p in self.named_parameters() if self.use_tgru or not n.startswith("TGRU.")]
 
