@@ -306,6 +306,55 @@ def streaming(args, dev, emit=True):
     print(json.dumps(out), flush=True)
 
 
+def streaming_audio(args, dev):
+    """stream.py:83-109 protocol on the GPU: 1024 concurrent streams, one hop of 128 new samples (8 ms) per stream and step,
+    audio in -> denoised audio out: trunet_stream_features (ring + rFFT-512 + features + PCEN state) -> trunet_stream_fwd (the
+    network, optionally with the TGRU state) -> trunet_stream_mask_istft (mask + irFFT + overlap-add tail).  The steady-state
+    hop is captured once as a hipGraph and replayed."""
+    from tinyrecurrentunet_amd import network as hn
+    from tinyrecurrentunet_amd.streaming import AudioStream
+    streams = 1024
+    torch.manual_seed(0)
+    net = hn.TRUNet(input_size=4).to(dev).eval()
+    net.fold_verify = False
+    st = AudioStream(net, streams, tgru=args.tgru)
+    chunk = 0.1 * torch.randn(streams, 128, device=dev)
+    for _ in range(max(args.warmup, 6)):            # past the analysis window's warm-up: steady-state hops
+        st.push(chunk)
+    torch.cuda.synchronize()
+    g, graphed = None, False
+    if not os.environ.get("TRUNET_NO_GRAPH"):
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = st._frame(chunk)
+            g.replay()
+            torch.cuda.synchronize()
+            graphed = True
+        except Exception as e:
+            print("[streaming] graph capture unavailable: %r" % (e,), file=sys.stderr)
+            g = None
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(args.steps):
+        chunk.normal_()
+        if g is not None:
+            g.replay()
+        else:
+            out = st._frame(chunk)
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / args.steps
+    out_ = {"metric": "streaming audio-in -> audio-out real-time factor (1024 streams x 1 hop of 128 samples)",
+            "value": round(streams * 0.008 / dt, 1), "unit": "x real time", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True, "dtype": "f32",
+            "data": "synthetic", "hip_graph": graphed, "vs_baseline": None, "launches_per_hop": 3,
+            "config": {"workload": "config/tiny.json TRU-Net causal audio stream: STFT frame + PCEN state -> eval forward%s -> "
+                                   "mask + iSTFT overlap-add, 1024 streams x 128 samples per step (stream.py protocol)" % (
+                                       " + stateful TGRU step" if args.tgru else "")},
+            "roofline": None, "cpu_baseline": None}
+    print(json.dumps(out_), flush=True)
+
+
 def other_configs(args, dev, step_factory):
     """Short measurements of BASELINE.json configs[2] (bf16 train step, this GPU's share) and configs[3] (1024-stream
     forward), attached to the headline line as context (`other_configs`); each is its own bench mode with its own
@@ -361,6 +410,9 @@ def main():
                     help="extension: TGRU block over time (use_tgru train step; with --streaming: stateful stream_step)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32: BASELINE.json configs[1] (headline); bf16: configs[2] storage/MFMA precision (extension)")
+    ap.add_argument("--audio", action="store_true",
+                    help="with --streaming: audio in -> audio out (stateful STFT / PCEN / overlap-add around the forward; "
+                         "stream.py:83-109 protocol), one hop of 128 samples per stream and step")
     ap.add_argument("--streaming", action="store_true",
                     help="BASELINE.json configs[3]: 1-frame causal forward of 1024 concurrent streams (rt.py protocol)")
     args = ap.parse_args()
@@ -397,7 +449,7 @@ def main():
 
     from tinyrecurrentunet_amd import distributed as tdist, engine, network as hn, optim, stft_loss as sl, util
     if args.streaming:
-        return streaming(args, dev)
+        return streaming_audio(args, dev) if args.audio else streaming(args, dev)
     cin = 3 if args.no_pcen else 4
     torch.manual_seed(0)                      # train.py:12-14
     net = hn.TRUNet(input_size=cin, use_tgru=args.tgru,
