@@ -262,16 +262,17 @@ def test_folded_cache_sees_weight_writes_through_dot_data():
         s0 = net.stream_step(x)[0]
         v0 = tuple(p._version for p in net.parameters())
         net.encoder[2].DepthwiseSeparableConv1d[0].weight.data.mul_(1.5)          # raw write: no version moves
+        net.encoder[2].DepthwiseSeparableConv1d[0].bias.data.add_(0.5)
         net.TGRU.conv[0].weight.data.mul_(0.5)
         assert tuple(p._version for p in net.parameters()) == v0
         y1 = net(x)
-        assert _rel(y1, y0) > 1e-3
+        assert _rel(y1, y0) > 1e-4
         assert torch.equal(y1, fresh_out())
         s1 = net.stream_step(x)[0]
-        assert _rel(s1, s0) > 1e-3 and torch.equal(s1, fresh_out(stream=True))
+        assert _rel(s1, s0) > 1e-4 and torch.equal(s1, fresh_out(stream=True))
         util.weight_scaling_init(net.decoder[1].TrCNN[0])                          # the reference's own idiom
         y2 = net(x)
-        assert _rel(y2, y1) > 1e-4 and torch.equal(y2, fresh_out())
+        assert not torch.equal(y2, y1) and torch.equal(y2, fresh_out())
         # opt-out for serving loops with frozen weights: no checksum, explicit invalidation
         net.fold_verify = False
         net(x)
@@ -279,7 +280,7 @@ def test_folded_cache_sees_weight_writes_through_dot_data():
         assert torch.equal(net(x), y2)                                             # stale by contract
         net.invalidate_folded()
         y3 = net(x)
-        assert _rel(y3, y2) > 1e-4 and torch.equal(y3, fresh_out())
+        assert not torch.equal(y3, y2) and torch.equal(y3, fresh_out())
 
 
 @pytest.mark.parametrize("N", [1, 255, 1024, 2500])

@@ -1,0 +1,129 @@
+"""GPU: conv_gemm_x3_kernel (gemm_x3.hip) -- the forward implicit GEMM on the bf16 MFMA with an exact three-term split of the
+fp32 operands -- against the fp32-MFMA kernel it replaces (same entry point, trunet_gemm_x3_enable(0)) and against a float64
+product of the same fp32 operands.  The claim under test: it IS an fp32 GEMM (24 significant bits per product, fp32
+accumulation), so its error against float64 must be of the size of the fp32-MFMA kernel's own."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ref(W, ldw_m, ldw_c, w_m_off, M, segs, bias, P, out_L, out_pos_off, NP):
+    """float64: out[m][p + off][n] = bias[m] + sum_seg sum_c W[m + w_m_off, c, seg] * pro(src[c][q(p)][n])"""
+    out = torch.zeros(M, out_L, NP, dtype=torch.float64, device=DEV)
+    Wf = W.double().reshape(-1)
+    for p in range(P):
+        acc = torch.zeros(M, NP, dtype=torch.float64, device=DEV)
+        for s in segs:
+            qn = p * s["mul"] + s["off"]
+            if qn < 0 or qn % s["div"] or qn // s["div"] >= s["x"].shape[1]:
+                continue
+            v = s["x"][:, qn // s["div"]].double()
+            if s.get("c0") is not None:
+                v = torch.relu(s["c0"].double()[:, None] * v + s["c1"].double()[:, None])
+            C = v.shape[0]
+            idx = (torch.arange(M, device=DEV)[:, None] + w_m_off) * ldw_m + torch.arange(C, device=DEV)[None, :] * ldw_c + s["woff"]
+            acc += Wf[idx] @ v
+        out[:, p + out_pos_off] = acc + (bias.double()[:, None] if bias is not None else 0.0)
+    return out
+
+
+def _run(M, segs, W, ldw_m, ldw_c, P, N, NP, bias=True, w_m_off=0, out_L=None, out_pos_off=0):
+    from tinyrecurrentunet_amd import _lib as L
+    from tinyrecurrentunet_amd._lib import PRO_BNRELU, PRO_NONE, make_seg
+    from tinyrecurrentunet_amd.engine import TRUNetEngine, Workspace
+    import ctypes as C
+    out_L = out_L or P
+    b = (torch.randn(M, device=DEV) * 0.3) if bias else None
+    sg = lambda: [make_seg(s["x"], s["x"].shape[0], s["x"].shape[1], s["mul"], s["off"], s["div"], s["woff"],
+                           PRO_BNRELU if s.get("c0") is not None else PRO_NONE, c0=s.get("c0"), c1=s.get("c1")) for s in segs]
+    res = {}
+    lib = L.lib()
+    prev = lib.trunet_gemm_x3_enable(-1)
+    try:
+        for mode in (1, 0):
+            lib.trunet_gemm_x3_enable(mode)
+            eng, w = TRUNetEngine(None), Workspace(torch.device(DEV))
+            out = torch.full((M, out_L, NP), float("nan"), device=DEV)
+            a = eng._gemm_args(N=N, NP=NP, P=P, M=M, out=out, out_L=out_L, W=W, ldw_m=ldw_m, ldw_c=ldw_c, segs=sg(), bias=b)
+            v = [C.c_int() for _ in range(6)]
+            L.check(lib.trunet_conv_gemm_plan(a, *[C.byref(x) for x in v]), "plan")
+            assert (v[5].value == -8) == (mode == 1), "x3 %s but the plan says nw = %d" % ("on" if mode else "off", v[5].value)
+            nparts = eng._gemm(w, N=N, NP=NP, P=P, M=M, out=out, out_L=out_L, W=W, ldw_m=ldw_m, ldw_c=ldw_c, segs=sg(),
+                               bias=b, w_m_off=w_m_off, out_pos_off=out_pos_off, stats=M)
+            torch.cuda.synchronize()
+            st = w.t["partials"][:nparts * M * 2].view(nparts, M, 2).double().sum(0)
+            res[mode] = (out.clone(), st)
+    finally:
+        lib.trunet_gemm_x3_enable(prev)
+    ref = _ref(W, ldw_m, ldw_c, w_m_off, M, segs, b, P, out_L, out_pos_off, NP)
+    rows = slice(out_pos_off, out_pos_off + P)
+    scale = ref[:, rows].abs().max().item()
+    e3 = (res[1][0][:, rows].double() - ref[:, rows]).abs().max().item() / scale
+    e1 = (res[0][0][:, rows].double() - ref[:, rows]).abs().max().item() / scale
+    l3 = ((res[1][0][:, rows].double() - ref[:, rows]).norm() / ref[:, rows].norm()).item()
+    l1 = ((res[0][0][:, rows].double() - ref[:, rows]).norm() / ref[:, rows].norm()).item()
+    print("M%d K%s P%d: vs float64 max-abs / max|out|: x3 %.2e fp32-MFMA %.2e; relative L2: x3 %.2e fp32-MFMA %.2e" % (
+        M, "+".join(str(s["x"].shape[0]) for s in segs), P, e3, e1, l3, l1))
+    assert torch.isfinite(res[1][0][:, rows]).all()
+    assert l3 < 2.0 * l1 + 1e-7 and e3 < 3.0 * e1 + 2e-7, (e3, e1, l3, l1)
+    # statistics (sum, sum of squares over the N valid frames) of both kernels agree with the float64 ones
+    r = ref[:, rows, :N]
+    st_ref = torch.stack([r.sum((1, 2)), (r * r).sum((1, 2))], 1)
+    for mode in (1, 0):
+        d = (res[mode][1] - st_ref).abs().max().item() / st_ref.abs().max().item()
+        assert d < 2e-5, (mode, d)
+    return res
+
+
+def _x(C, Ln, NP, N, g):
+    x = torch.randn(C, Ln, NP, generator=g, device=DEV)
+    x[:, :, N:] = 0.0                          # padding frames: finite
+    return x
+
+
+@pytest.mark.parametrize("M,K,P,N", [(128, 128, 7, 700), (128, 64, 5, 257), (64, 64, 4, 1000)])
+def test_x3_pointwise_one_source(M, K, P, N):
+    g = torch.Generator(device=DEV).manual_seed(M + K + P)
+    NP = (N + 255) // 256 * 256
+    W = torch.randn(M, K, generator=g, device=DEV) * 0.2
+    seg = dict(x=_x(K, P, NP, N, g), mul=1, off=0, div=1, woff=0, c0=torch.rand(K, generator=g, device=DEV) + 0.5,
+               c1=torch.randn(K, generator=g, device=DEV) * 0.3)
+    _run(M, [seg], W, K, 1, P, N, NP)
+
+
+def test_x3_decoder_pointwise_two_sources_with_pad():
+    """decoder pointwise conv over [x1 shifted by F.pad | skip] (network.py:95-100): M = 64, K = 64 + 128"""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    N, NP, P = 600, 768, 8
+    W = torch.randn(64, 192, generator=g, device=DEV) * 0.15
+    mk = lambda C, Ln: dict(x=_x(C, Ln, NP, N, g), mul=1, div=1, c0=torch.rand(C, generator=g, device=DEV) + 0.5,
+                            c1=torch.randn(C, generator=g, device=DEV) * 0.3)
+    s1 = dict(mk(64, 7), off=-1, woff=0)               # one position of left padding
+    s2 = dict(mk(128, 8), off=0, woff=64)
+    _run(64, [s1, s2], W, 192, 1, P, N, NP)
+
+
+@pytest.mark.parametrize("k,s", [(3, 1), (5, 2), (3, 2)])
+def test_x3_transposed_conv_taps(k, s):
+    """ConvTranspose1d(64 -> 64, k, s, padding = s // 2) as a gather over its taps (network.py:67,86): weight (Ci, Co, k)"""
+    g = torch.Generator(device=DEV).manual_seed(10 * k + s)
+    N, NP, Lin = 300, 512, 6
+    pad = s // 2
+    Lo = (Lin - 1) * s - 2 * pad + k
+    W = torch.randn(64, 64, k, generator=g, device=DEV) * 0.2         # (Ci, Co, k): ldw_m = k, ldw_c = Co * k, woff = tap
+    x = _x(64, Lin, NP, N, g)
+    c0, c1 = torch.rand(64, generator=g, device=DEV) + 0.5, torch.randn(64, generator=g, device=DEV) * 0.3
+    segs = [dict(x=x, mul=1, off=pad - kk, div=s, woff=kk, c0=c0, c1=c1) for kk in range(k)]
+    _run(64, segs, W, k, 64 * k, Lo, N, NP)
+
+
+def test_x3_gru_projection_three_row_blocks():
+    """M = 384 = three 128-row blocks of one launch (the FGRU input projection, network.py:48), plain prologue"""
+    g = torch.Generator(device=DEV).manual_seed(9)
+    N, NP, P = 500, 512, 4
+    W = torch.randn(384, 128, generator=g, device=DEV) * 0.1
+    seg = dict(x=_x(128, P, NP, N, g), mul=1, off=0, div=1, woff=0)
+    _run(384, [seg], W, 128, 1, P, N, NP)

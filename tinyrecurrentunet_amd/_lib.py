@@ -145,6 +145,7 @@ def _declare(L):
     i, d, f, p, i64 = C.c_int, C.c_double, C.c_float, _fp, C.c_int64
     sig = {
         "trunet_conv_gemm_nparts": [i],
+        "trunet_gemm_x3_enable": [i],
         "trunet_conv_gemm": [C.POINTER(GemmArgs), p],
         "trunet_conv_gemm_plan": [C.POINTER(GemmArgs)] + [C.POINTER(C.c_int)] * 6,
         "trunet_conv_wgrad_nparts": [],

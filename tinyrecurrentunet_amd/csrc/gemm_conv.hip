@@ -601,8 +601,21 @@ int plan_gemm(const trunet_gemm_args* h, GemmPlan* pl) {
 
 }  // namespace
 
+// gemm_x3.hip: the three-term bf16-split kernel for the launches without a tensor-operand epilogue
+int trunet_gemm_x3_plan(const trunet_gemm_args* h, int* nb, size_t* lds);
+int trunet_launch_gemm_x3(const trunet_gemm_args* h, int nrt, int nb, size_t lds, hipStream_t st);
+
 extern "C" int trunet_conv_gemm_plan(const trunet_gemm_args* h, int* rs, int* kc, int* nb, int* two, int* epl, int* nw) {
     if (!h || !rs || !kc || !nb || !two || !epl || !nw) return TRUNET_EINVAL;
+    {
+        int xnb = 0;
+        size_t xlds = 0;
+        const int nrt = (h->M > 8) ? trunet_gemm_x3_plan(h, &xnb, &xlds) : 0;
+        if (nrt) {          // conv_gemm_x3_kernel<NRT>: reported as rs = NRT, kc = 16, nw = -8 (bf16x3 MFMA)
+            *rs = nrt; *kc = 16; *nb = xnb; *two = 0; *epl = 0; *nw = -8;
+            return TRUNET_OK;
+        }
+    }
     GemmPlan pl;
     if (plan_gemm(h, &pl) != TRUNET_OK) return TRUNET_ENOTSUP;
     *rs = pl.rs; *kc = pl.kc; *nb = pl.nb; *two = pl.two ? 1 : 0; *epl = pl.epl; *nw = pl.nw;
@@ -646,6 +659,12 @@ extern "C" int trunet_conv_gemm(const trunet_gemm_args* h, void* stream) {
         if (hipMemsetAsync(h->partials, 0, bytes, st) != hipSuccess) return TRUNET_ELAUNCH;
     }
     if (h->M <= 8 && !any_two) return launch_smallm(h, st);
+    {
+        int xnb = 0;
+        size_t xlds = 0;
+        const int nrt = trunet_gemm_x3_plan(h, &xnb, &xlds);
+        if (nrt) return trunet_launch_gemm_x3(h, nrt, xnb, xlds, st);
+    }
     switch (pl.rs) {
         case 4: return launch_gemm_rs<4>(h, pl.kc, pl.two, pl.epl, pl.nb, pl.lds, st, pl.nw);
         case 2: return launch_gemm_rs<2>(h, pl.kc, pl.two, pl.epl, pl.nb, pl.lds, st, pl.nw);

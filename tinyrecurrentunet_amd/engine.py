@@ -86,6 +86,8 @@ def _gemm_kernel_name(a):
     rs, kc, nb, two, epl, nw = [x.value for x in v]
     if a.M <= 8 and not two:
         return "conv_smallm_kernel<%d>" % epl
+    if nw < 0:              # the three-term bf16-split kernel (gemm_x3.hip)
+        return "conv_gemm_x3_kernel<%d>" % rs
     return "conv_gemm_kernel<%d, %d, %s, %d, %d>" % (rs, kc, "true" if two else "false", epl, nw)
 
 
