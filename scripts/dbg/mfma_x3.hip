@@ -1,7 +1,7 @@
 // Diagnostic: is a three-term bf16 split of fp32 operands on the bf16 MFMA a faster fp32-grade GEMM
 // inner loop than the fp32 MFMA on this chip?
 //
-//   x = b0 + b1 + b2 exactly (three truncations: 8 + 8 + 8 significand bits), products b0b0, b0b1, b1b0, b0b2, b1b1, b2b0
+//   x = b0 + b1 + b2 (8 + 8 + 8 significand bits, each term rounded to nearest), products b0b0, b0b1, b1b0, b0b2, b1b1, b2b0
 //   on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 6 x 33 cycles per (32 x 32 x 16) against 8 x 64 for
 //   v_mfma_f32_32x32x2_f32.
 //
@@ -26,8 +26,16 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int M = 128, KC = 32, FT = 256;      // rows of the weight block, K rows per chunk, frames per tile
 
-// exact three-way truncation split of two floats, packed: element 0 in the low half
+// three-way split of two floats into bf16 terms rounded to nearest (the form gemm_x3.hip uses), packed: element 0 in the
+// low half.  -DX3_TRUNC: the truncating form (and / sub: exact, but biased towards zero in the dropped cross terms)
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk(float a, float b) {
+    const f32x2_ v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_));
+}
 __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+#ifdef X3_TRUNC
     const unsigned b0 = __float_as_uint(x0), b1 = __float_as_uint(x1);
     hi = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
     const float r0 = x0 - __uint_as_float(b0 & 0xFFFF0000u), r1 = x1 - __uint_as_float(b1 & 0xFFFF0000u);
@@ -35,6 +43,12 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
     mid = __builtin_amdgcn_perm(c1, c0, 0x07060302u);
     const float s0 = r0 - __uint_as_float(c0 & 0xFFFF0000u), s1 = r1 - __uint_as_float(c1 & 0xFFFF0000u);
     lo = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+#else
+    hi = pk(x0, x1);
+    const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xFFFF0000u);
+    mid = pk(r0, r1);
+    lo = pk(r0 - __uint_as_float(mid << 16), r1 - __uint_as_float(mid & 0xFFFF0000u));
+#endif
 }
 
 // LDS images (floats): A32 [4 rs][16 kp][64 lanes] (k-pair fragments of v_mfma_f32_32x32x2_f32), B32 [32][256],

@@ -1,8 +1,8 @@
-// fp32 implicit-GEMM convolution on the bf16 MFMA with an EXACT three-way operand split (round 4).
+// fp32 implicit-GEMM convolution on the bf16 MFMA with a three-way (24-bit) operand split (round 4).
 //
 // The fp32 MFMA of this chip runs at the packed-fp32 vector rate (157 TF); the bf16 MFMA at 16x that.  Every fp32 number is
-// the exact sum of three bf16 numbers, x = x0 + x1 + x2 (three truncations: 8 + 8 + 8 significand bits, the residues are
-// exact), and a product of two bf16 numbers is exact in fp32, so
+// the sum of three bf16 numbers, x = x0 + x1 + x2 (8 + 8 + 8 significand bits, each term rounded to nearest, the residues
+// exact in fp32), and a product of two bf16 numbers is exact in fp32, so
 //     a b = a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0) + O(2^-24 |a b|)
 // is six v_mfma_f32_32x32x16_bf16 with fp32 accumulation per 16 K-values -- 6 x 33 cycles against 8 x 64 for
 // v_mfma_f32_32x32x2_f32 -- and carries the same 24 significant bits per product as an fp32 FMA chain (the three dropped
@@ -31,15 +31,15 @@ namespace {
 constexpr int X3_KC = 16;          // K rows per chunk = one MFMA K-step
 constexpr int X3_FT = 256;         // frames per tile (8 waves x 32)
 
-// exact three-way truncation split of two floats, packed (element 0 in the low half)
+// three-way split of two floats into bf16 terms, packed (element 0 in the low half): x = hi + mid + lo with every term
+// rounded to NEAREST (v_cvt_pk_bf16_f32), so the residues are signed and zero-mean: hi carries 8 significand bits, x - hi
+// is exact in fp32, mid its leading 8 bits, lo the rest (exact up to one unit in the 25th bit).  Same instruction count
+// as a truncating split (and / sub), without its bias towards zero in the dropped cross terms.
 __device__ __forceinline__ void x3_split2(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
-    const unsigned b0 = __float_as_uint(x0), b1 = __float_as_uint(x1);
-    hi = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
-    const float r0 = x0 - __uint_as_float(b0 & 0xFFFF0000u), r1 = x1 - __uint_as_float(b1 & 0xFFFF0000u);
-    const unsigned c0 = __float_as_uint(r0), c1 = __float_as_uint(r1);
-    mid = __builtin_amdgcn_perm(c1, c0, 0x07060302u);
-    const float s0 = r0 - __uint_as_float(c0 & 0xFFFF0000u), s1 = r1 - __uint_as_float(c1 & 0xFFFF0000u);
-    lo = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+    hi = bf_pack(x0, x1);
+    const float r0 = x0 - bf_lo(hi), r1 = x1 - bf_hi(hi);
+    mid = bf_pack(r0, r1);
+    lo = bf_pack(r0 - bf_lo(mid), r1 - bf_hi(mid));
 }
 
 // counted wait for the LDS-DMA ring (2 instructions per wave and chunk); the large counts are used while the stores of a
@@ -179,6 +179,26 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_kernel(const trunet_gemm_
         };
 
         if (wave8 >= 4) __builtin_amdgcn_s_setprio(1);
+        // ---- software pipeline over the flattened chunk stream (chunk j lives in ring slot j % NB):
+        //   iteration i:  request B(i+1) from LDS -> 6 NRT MFMAs of chunk i on the fragments split one iteration ago ->
+        //                 in-place prologue of chunk i+2 (its DMA was issued NB-1 iterations ago) -> split B(i+1) ->
+        //                 barrier -> DMA of chunk i+1+NB into the slot B(i+1) was read from.
+        // The matrix pipe starts right after the barrier (nothing of chunk i is read from the ring any more) and the
+        // vector work of the next chunk runs behind the issued MFMAs; the first version did read -> split -> MFMA inside
+        // one barrier interval and left the pipe idle for a third of it (100 TF-equivalent at 128 x 128).
+        auto read_b = [&](int sl, float (&x)[8]) {
+            const float* Bb = R_lds + (size_t)sl * CHF + 32 * wave8 + c;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = Bb[(8 * h + j) * FT];
+        };
+        auto split_b = [&](const float (&x)[8], u32x4& q0, u32x4& q1, u32x4& q2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned u0, u1, u2;
+                x3_split2(x[2 * j], x[2 * j + 1], u0, u1, u2);
+                q0[j] = u0; q1[j] = u1; q2[j] = u2;
+            }
+        };
         it_enter_tile<KC, FT>(a, cur);
         ChunkIt ld = cur, ldlast = cur;
         for (int d = 0; d < NB; ++d) {
@@ -188,13 +208,30 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_kernel(const trunet_gemm_
         }
         ChunkIt tf = cur;
         int tslot = 0;
-        x3_wait_vmcnt((NB - 1) * LPW);
-        transform(tf, tslot);
+        x3_wait_vmcnt((NB - 2) * LPW);                  // chunks 0 and 1 have landed
+        transform(tf, 0);
         it_next<KC, FT>(a, tf);
         tslot = 1;
+        if (tf.valid) {
+            transform(tf, 1);
+            it_next<KC, FT>(a, tf);
+            tslot = (2 == NB) ? 0 : 2;
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        u32x4 bp0, bp1, bp2;
+        {
+            float x[8];
+            read_b(0, x);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();               // every wave holds B(0): slot 0 takes chunk NB
+            asm volatile("" ::: "memory");
+            if (ld.valid) ldlast = ld;
+            issue_dma(ldlast, 0);
+            if (ld.valid) it_next<KC, FT>(a, ld);
+            split_b(x, bp0, bp1, bp2);
+        }
 
         int slot = 0;
         // Chunks since the last epilogue.  Its 16 NRT stores per lane are YOUNGER than the NB - 1 chunks of DMA requested
@@ -203,69 +240,77 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_kernel(const trunet_gemm_
         // does not drain the tile's stores.
         int since_epi = NB;
         const int relaxed = min(63, (NB - 2) * LPW + 16 * NRT);
-        while (cur.valid) {                              // ---- tiles
-            f32x16 acc[NRT];
+        bool first = true;
+        int tp = 0, nn = 0, tn0 = 0;
+        f32x16 acc[NRT];
+        // output rows as buffer resource (uniform base of the tile's row block) + one per-lane offset (4 h rows down, this
+        // lane's frame) + a scalar row offset: 64 per-row 64-bit addresses do not fit next to 64 accumulators
+        const size_t rowstride = (size_t)a.out_L * a.NP;
+        const int rowb = (int)(rowstride * sizeof(float));
+        const int voff = (int)((4 * h * rowstride + 32 * wave8 + c) * sizeof(float));
+        while (cur.valid) {
+            if (first) {
 #pragma unroll
-            for (int t = 0; t < NRT; ++t)
+                for (int t = 0; t < NRT; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-            const int tp = cur.p;
-            const int nn = cur.n0 + 32 * wave8 + c;      // this lane's frame
-            bool last = false;
-            while (!last) {                              // ---- chunks of the tile
-                ChunkIt nxt = cur;
-                last = it_next<KC, FT>(a, nxt);
-                if (tf.valid) {                          // prologue pass on the next chunk (DMA issued NB-1 chunks ago)
-                    x3_wait_vmcnt(since_epi < NB - 1 ? relaxed : (NB - 2) * LPW);
-                    ++since_epi;
-                    transform(tf, tslot);
-                    it_next<KC, FT>(a, tf);
-                    tslot = (tslot + 1 == NB) ? 0 : tslot + 1;
-                }
-                {
-                    const float* Bb = R_lds + (size_t)slot * CHF + 32 * wave8 + c;
-                    float x[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) x[j] = Bb[(8 * h + j) * FT];
-                    u32x4 bp0, bp1, bp2;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        unsigned u0, u1, u2;
-                        x3_split2(x[2 * j], x[2 * j + 1], u0, u1, u2);
-                        bp0[j] = u0; bp1[j] = u1; bp2[j] = u2;
-                    }
-                    const u32x4* Ab = A3 + ((size_t)(cur.ach + cur.cc) * NRT * 3) * 64 + lane;
-#pragma unroll
-                    for (int t = 0; t < NRT; ++t) {
-                        const u32x4 a0 = Ab[(t * 3 + 0) * 64], a1 = Ab[(t * 3 + 1) * 64], a2 = Ab[(t * 3 + 2) * 64];
-#define X3_MF(a_, b_) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), acc[t], 0, 0, 0)
-                        // the small cross terms first, the leading term last
-                        X3_MF(a2, bp0); X3_MF(a0, bp2); X3_MF(a1, bp1); X3_MF(a1, bp0); X3_MF(a0, bp1); X3_MF(a0, bp0);
-#undef X3_MF
-                    }
-                }
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                if (ld.valid) ldlast = ld;
-                issue_dma(ldlast, slot);                 // slot `slot` is free for everyone now
-                if (ld.valid) it_next<KC, FT>(a, ld);
-                slot = (slot + 1 == NB) ? 0 : slot + 1;
-                cur = nxt;
+                    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+                tp = cur.p;
+                tn0 = cur.n0;
+                nn = cur.n0 + 32 * wave8 + c;            // this lane's frame
+                first = false;
             }
+            ChunkIt nxt = cur;
+            const bool last = it_next<KC, FT>(a, nxt);
+            const int nslot = (slot + 1 == NB) ? 0 : slot + 1;
+            float x[8];
+            read_b(nslot, x);                            // B of the NEXT chunk (published by the previous barrier)
+            {
+                const u32x4* Ab = A3 + ((size_t)(cur.ach + cur.cc) * NRT * 3) * 64 + lane;
+#pragma unroll
+                for (int t = 0; t < NRT; ++t) {
+                    const u32x4 a0 = Ab[(t * 3 + 0) * 64], a1 = Ab[(t * 3 + 1) * 64], a2 = Ab[(t * 3 + 2) * 64];
+#define X3_MF(a_, b_) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), acc[t], 0, 0, 0)
+                    // the small cross terms first, the leading term last
+                    X3_MF(a2, bp0); X3_MF(a0, bp2); X3_MF(a1, bp1); X3_MF(a1, bp0); X3_MF(a0, bp1); X3_MF(a0, bp0);
+#undef X3_MF
+                }
+            }
+            if (tf.valid) {                              // prologue pass on chunk i + 2
+                x3_wait_vmcnt(since_epi < NB - 1 ? relaxed : (NB - 2) * LPW);
+                ++since_epi;
+                transform(tf, tslot);
+                it_next<KC, FT>(a, tf);
+                tslot = (tslot + 1 == NB) ? 0 : tslot + 1;
+            }
+            u32x4 bn0, bn1, bn2;
+            split_b(x, bn0, bn1, bn2);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (ld.valid) ldlast = ld;
+            issue_dma(ldlast, nslot);                    // every wave holds B(i+1): its slot takes chunk i + 1 + NB
+            if (ld.valid) it_next<KC, FT>(a, ld);
+            bp0 = bn0; bp1 = bn1; bp2 = bn2;
+            slot = nslot;
+            cur = nxt;
+            if (!last) continue;
             // ---- epilogue of the tile: bias (+ ReLU), 128-byte row pieces per half-wave, statistics through the butterfly
             since_epi = 0;
+            first = true;
 #pragma unroll
             for (int t = 0; t < NRT; ++t) {
                 float s1[16], s2[16];
+                const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+                    a.out + ((size_t)(mblk * MB + 32 * t + a.m_out_off) * a.out_L + tp + a.out_pos_off) * a.NP + tn0, 0,
+                    0x7fffffff, 0x00020000);
+                const bool fin = nn < a.N;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int ml = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const int m = mblk * MB + ml;
-                    float val = acc[t][r] + E_lds[ml];
+                    const int ml = (r & 3) + 8 * (r >> 2);          // (+ 4 h: in voff); M is a multiple of 32 here
+                    float val = acc[t][r] + E_lds[32 * t + ml + 4 * h];
                     if (a.epi & TRUNET_EPI_RELU) val = fmaxf(val, 0.f);
-                    if (m < a.M) a.out[((size_t)(m + a.m_out_off) * a.out_L + tp + a.out_pos_off) * a.NP + nn] = val;
-                    const float xs = (nn < a.N && m < a.M) ? val : 0.f;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, val), ro, voff, ml * rowb, 0);
+                    const float xs = fin ? val : 0.f;
                     s1[r] = xs;
                     s2[r] = xs * xs;
                 }
