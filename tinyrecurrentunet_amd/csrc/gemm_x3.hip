@@ -143,83 +143,41 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_kernel(const trunet_gemm_
     __syncthreads();
 
     if (has_work) {
-        // ---- the chunk stream of this workgroup, generated from REGISTER-RESIDENT segment tables.  The shared iterator of
-        // gemm_common.hpp indexes `a.seg[s]` with a run-time s: every field is a scalar load from the kernel-argument
-        // segment followed by s_waitcnt lgkmcnt(0) (which also drains the LDS queue) -- a dozen dependent round trips per
-        // chunk, tolerable at 32-row chunks next to fp32 MFMAs, the whole critical path at 16-row chunks next to bf16 ones.
-        // Here the per-segment constants sit in table registers (lane q = segment q, selected by v_readlane with a scalar
-        // index), the set of segments valid at a position is a ballot computed once per tile, and "next valid segment" is
-        // a find-first-set.
-        // lane q of each table register holds segment q's constant; a selection is ONE v_readlane with a scalar index
-        int T_nchan, T_nck, T_cbase, T_ach, T_mul, T_off, T_sh, T_L;
-        unsigned T_srclo, T_srchi;
-        {
-            const int q = min(lane, a.nseg - 1);
-            const bool on = lane < a.nseg;
-            const trunet_seg& sq = a.seg[q];
-            T_nchan = on ? sq.nchan : 1;
-            T_nck = (T_nchan + KC - 1) / KC;
-            T_mul = on ? sq.pos_mul : 0; T_off = on ? sq.pos_off : -1;
-            T_sh = on ? (sq.pos_div >> 1) : 0; T_L = on ? sq.L : 0;
-            const unsigned long long sp = (unsigned long long)sq.src0;
-            T_srclo = (unsigned)sp; T_srchi = (unsigned)(sp >> 32);
-            int cb = 0, ac = 0;
-            for (int j = 0; j < TRUNET_MAX_SEG; ++j) {
-                if (j < lane && j < a.nseg) { cb += a.seg[j].nchan; ac += (a.seg[j].nchan + KC - 1) / KC; }
-            }
-            T_cbase = cb; T_ach = ac;
-        }
-#define X3_SEL(tab, sidx) __builtin_amdgcn_readlane(tab, sidx)
-        // bit q set: segment q is valid at output position p (seg_pos of gemm_common.hpp); lane q evaluates segment q
-        auto valid_mask = [&](int p) -> unsigned {
-            const int qn = p * T_mul + T_off;
-            const bool ok = (qn >= 0) && ((qn & T_sh) == 0) && ((qn >> T_sh) < T_L);
-            return (unsigned)__builtin_amdgcn_ballot_w64(ok) & 0x1fu;
-        };
-        struct Gen { int tile, tile_end, p, n0, s, cc; unsigned vm; bool valid; };
-        Gen gen;
-        gen.tile = cur.tile; gen.tile_end = cur.tile_end;
-        {
-            const int nt = gen.tile / a.P;
-            gen.p = a.p_begin + (gen.tile - nt * a.P);
-            gen.n0 = nt * FT;
-        }
-        gen.valid = true;                               // has_work
-        gen.vm = valid_mask(gen.p);                     // host contract: >= 1 valid segment per position
-        gen.s = __builtin_ctz(gen.vm | 0x20u);
-        gen.cc = 0;
-        // LDS-DMA of the chunk `g` points at: 16 rows x 256 frames as 1-KiB wave-instructions, instruction r = row r of the
-        // chunk; wave w8 issues rows 2 w8, 2 w8 + 1 and later transforms exactly the bytes it requested
-        auto issue_dma = [&](const Gen& g, int slot) {
-            const int qn = g.p * X3_SEL(T_mul, g.s) + X3_SEL(T_off, g.s);
-            const int q = qn >> X3_SEL(T_sh, g.s);
+        // LDS-DMA of one chunk: 16 rows x 256 frames as 1-KiB wave-instructions, instruction g = row g of the chunk; wave w8
+        // issues rows 2 w8, 2 w8 + 1 and later transforms exactly the bytes it requested (no barrier of its own)
+        auto issue_dma = [&](const ChunkIt& it, int slot) {
+            const trunet_seg& sg = a.seg[it.s];
+            const int q = seg_pos(sg, it.p).q;
             float* dst = R_lds + (size_t)slot * CHF;
-            const size_t boff = (size_t)q * a.NP + g.n0;
-            const unsigned rstride = (unsigned)X3_SEL(T_L, g.s) * (unsigned)a.NP;
-            const float* b0 = (const float*)(((unsigned long long)(unsigned)X3_SEL((int)T_srchi, g.s) << 32) |
-                                             (unsigned)X3_SEL((int)T_srclo, g.s)) + boff;
-            const int nch = X3_SEL(T_nchan, g.s);
+            const size_t boff = (size_t)q * a.NP + it.n0;
+            const unsigned rstride = (unsigned)sg.L * (unsigned)a.NP;
+            const float* b0 = sg.src0 + boff;
 #pragma unroll
             for (int i = 0; i < LPW; ++i) {
-                const int r = LPW * wave8 + i;
-                const int cch = min(g.cc * KC + r, nch - 1);              // rows past the segment: finite filler (A = 0)
+                const int g = LPW * wave8 + i;
+                const int cch = min(it.cc * KC + g, sg.nchan - 1);        // rows past the segment: finite filler (A = 0)
                 const unsigned off = (unsigned)cch * rstride + (unsigned)(4 * lane);
-                __builtin_amdgcn_global_load_lds(b0 + off, (lds_ptr_t)(dst + r * FT), 16, 0, TRUNET_DMA_AUX);
+                __builtin_amdgcn_global_load_lds(b0 + off, (lds_ptr_t)(dst + g * FT), 16, 0, TRUNET_DMA_AUX);
             }
         };
-        // move g to the next chunk; true when that chunk belongs to another tile (or the stream ends)
-        auto advance = [&](Gen& g) -> bool {
-            if (++g.cc < X3_SEL(T_nck, g.s)) return false;
-            g.cc = 0;
-            const unsigned rest = g.vm >> (g.s + 1);
-            if (rest) { g.s += 1 + __builtin_ctz(rest); return false; }
-            ++g.tile;
-            if (++g.p == a.p_begin + a.P) { g.p = a.p_begin; g.n0 += FT; }      // tiles of a workgroup: consecutive, p fastest
-            g.valid = g.tile < g.tile_end;
-            g.vm = valid_mask(g.p);
-            g.s = __builtin_ctz(g.vm | 0x20u);
-            return true;
+        auto transform = [&](const ChunkIt& it, int slot) {
+            float* dst = R_lds + (size_t)slot * CHF;
+            const int nrow = a.seg[it.s].nchan - it.cc * KC;
+            f32x4 v[LPW], k[LPW];
+#pragma unroll
+            for (int i = 0; i < LPW; ++i) {
+                const int g = LPW * wave8 + i;
+                v[i] = *(const f32x4*)(dst + g * FT + 4 * lane);
+                k[i] = C_lds[it.cbase + it.cc * KC + min(g, nrow - 1)];
+            }
+#pragma unroll
+            for (int i = 0; i < LPW; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[i][e] = fmaxf(fmaf(v[i][e], k[i][0], k[i][1]), k[i][2]);
+#pragma unroll
+            for (int i = 0; i < LPW; ++i) *(f32x4*)(dst + (LPW * wave8 + i) * FT + 4 * lane) = v[i];
         };
+
         if (wave8 >= 4) __builtin_amdgcn_s_setprio(1);
         // ---- software pipeline over the flattened chunk stream (chunk j lives in ring slot j % NB):
         //   iteration i:  request B(i+1) from LDS -> 6 NRT MFMAs of chunk i on the fragments split one iteration ago ->
@@ -241,57 +199,22 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_kernel(const trunet_gemm_
                 q0[j] = u0; q1[j] = u1; q2[j] = u2;
             }
         };
-        // ONE chunk iterator (the DMA stage, furthest ahead) generates a small descriptor per chunk; the later stages
-        // (in-place prologue two chunks behind it ... MFMAs NB chunks behind it) read theirs from a shift register of
-        // NB + 1 descriptors in SGPRs.  Until this the loop advanced four copies of the full iterator per chunk: 484 scalar
-        // instructions and 70 branches between two barriers against 24 MFMAs (SQ counters: waves issuing 35-40 % of the
-        // time at 2 waves per SIMD, matrix pipe 30 % busy) -- at 16-row chunks the bookkeeping, not the pipe, set the pace.
-        struct Desc { int coef, nrow, achunk, p, n0; bool valid, last; };
-        auto describe = [&](Gen& g) -> Desc {          // descriptor of the chunk g points at; g moves on
-            Desc d;
-            d.valid = g.valid;
-            d.coef = X3_SEL(T_cbase, g.s) + g.cc * KC;
-            d.nrow = X3_SEL(T_nchan, g.s) - g.cc * KC;
-            d.achunk = X3_SEL(T_ach, g.s) + g.cc;
-            d.p = g.p;
-            d.n0 = g.n0;
-            d.last = g.valid ? advance(g) : true;
-            return d;
-        };
-        auto transform_d = [&](const Desc& d, int sl) {
-            float* dst = R_lds + (size_t)sl * CHF;
-            f32x4 v[LPW], k[LPW];
-#pragma unroll
-            for (int i = 0; i < LPW; ++i) {
-                const int g = LPW * wave8 + i;
-                v[i] = *(const f32x4*)(dst + g * FT + 4 * lane);
-                k[i] = C_lds[d.coef + min(g, d.nrow - 1)];
-            }
-#pragma unroll
-            for (int i = 0; i < LPW; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[i][e] = fmaxf(fmaf(v[i][e], k[i][0], k[i][1]), k[i][2]);
-#pragma unroll
-            for (int i = 0; i < LPW; ++i) *(f32x4*)(dst + (LPW * wave8 + i) * FT + 4 * lane) = v[i];
-        };
-        Gen glast = gen;
-        Desc Q[5];
-#pragma unroll
-        for (int d = 0; d < 5; ++d) { Q[d].valid = false; Q[d].last = true; Q[d].coef = 0; Q[d].nrow = 1; Q[d].achunk = 0; Q[d].p = 0; Q[d].n0 = 0; }
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            if (d < NB) {
-                if (gen.valid) glast = gen;
-                issue_dma(glast, d);                    // past the end: harmless re-load of the last chunk
-                Q[d] = describe(gen);
-            }
+        it_enter_tile<KC, FT>(a, cur);
+        ChunkIt ld = cur, ldlast = cur;
+        for (int d = 0; d < NB; ++d) {
+            if (ld.valid) ldlast = ld;
+            issue_dma(ldlast, d);                       // past the end: harmless re-load of the last chunk
+            if (ld.valid) it_next<KC, FT>(a, ld);
         }
+        ChunkIt tf = cur;
         int tslot = 0;
         x3_wait_vmcnt((NB - 2) * LPW);                  // chunks 0 and 1 have landed
-        transform_d(Q[0], 0);
+        transform(tf, 0);
+        it_next<KC, FT>(a, tf);
         tslot = 1;
-        if (Q[1].valid) {
-            transform_d(Q[1], 1);
+        if (tf.valid) {
+            transform(tf, 1);
+            it_next<KC, FT>(a, tf);
             tslot = (2 == NB) ? 0 : 2;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -304,10 +227,9 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_kernel(const trunet_gemm_
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();               // every wave holds B(0): slot 0 takes chunk NB
             asm volatile("" ::: "memory");
-            if (gen.valid) glast = gen;
-            issue_dma(glast, 0);
-            const Desc nd = describe(gen);
-            if (NB == 2) Q[2] = nd; else if (NB == 3) Q[3] = nd; else Q[4] = nd;
+            if (ld.valid) ldlast = ld;
+            issue_dma(ldlast, 0);
+            if (ld.valid) it_next<KC, FT>(a, ld);
             split_b(x, bp0, bp1, bp2);
         }
 
@@ -326,23 +248,24 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_kernel(const trunet_gemm_
         const size_t rowstride = (size_t)a.out_L * a.NP;
         const int rowb = (int)(rowstride * sizeof(float));
         const int voff = (int)((4 * h * rowstride + 32 * wave8 + c) * sizeof(float));
-        while (Q[0].valid) {
+        while (cur.valid) {
             if (first) {
 #pragma unroll
                 for (int t = 0; t < NRT; ++t)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-                tp = Q[0].p;
-                tn0 = Q[0].n0;
-                nn = Q[0].n0 + 32 * wave8 + c;           // this lane's frame
+                tp = cur.p;
+                tn0 = cur.n0;
+                nn = cur.n0 + 32 * wave8 + c;            // this lane's frame
                 first = false;
             }
-            const bool last = Q[0].last;
+            ChunkIt nxt = cur;
+            const bool last = it_next<KC, FT>(a, nxt);
             const int nslot = (slot + 1 == NB) ? 0 : slot + 1;
             float x[8];
             read_b(nslot, x);                            // B of the NEXT chunk (published by the previous barrier)
             {
-                const u32x4* Ab = A3 + ((size_t)Q[0].achunk * NRT * 3) * 64 + lane;
+                const u32x4* Ab = A3 + ((size_t)(cur.ach + cur.cc) * NRT * 3) * 64 + lane;
 #pragma unroll
                 for (int t = 0; t < NRT; ++t) {
                     const u32x4 a0 = Ab[(t * 3 + 0) * 64], a1 = Ab[(t * 3 + 1) * 64], a2 = Ab[(t * 3 + 2) * 64];
@@ -352,10 +275,11 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_kernel(const trunet_gemm_
 #undef X3_MF
                 }
             }
-            if (Q[2].valid) {                            // prologue pass on chunk i + 2
+            if (tf.valid) {                              // prologue pass on chunk i + 2
                 x3_wait_vmcnt(since_epi < NB - 1 ? relaxed : (NB - 2) * LPW);
                 ++since_epi;
-                transform_d(Q[2], tslot);
+                transform(tf, tslot);
+                it_next<KC, FT>(a, tf);
                 tslot = (tslot + 1 == NB) ? 0 : tslot + 1;
             }
             u32x4 bn0, bn1, bn2;
@@ -363,13 +287,12 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_kernel(const trunet_gemm_
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (gen.valid) glast = gen;
-            issue_dma(glast, nslot);                     // every wave holds B(i+1): its slot takes chunk i + 1 + NB
-            const Desc nd = describe(gen);
-            Q[0] = Q[1]; Q[1] = Q[2]; Q[2] = Q[3]; Q[3] = Q[4];
-            if (NB == 2) Q[2] = nd; else if (NB == 3) Q[3] = nd; else Q[4] = nd;
+            if (ld.valid) ldlast = ld;
+            issue_dma(ldlast, nslot);                    // every wave holds B(i+1): its slot takes chunk i + 1 + NB
+            if (ld.valid) it_next<KC, FT>(a, ld);
             bp0 = bn0; bp1 = bn1; bp2 = bn2;
             slot = nslot;
+            cur = nxt;
             if (!last) continue;
             // ---- epilogue of the tile: bias (+ ReLU), 128-byte row pieces per half-wave, statistics through the butterfly
             since_epi = 0;
@@ -398,7 +321,6 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_kernel(const trunet_gemm_
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the ring before the workgroup exits
-#undef X3_SEL
     }
 
     if (a.epi & TRUNET_EPI_STATS) {
