@@ -84,8 +84,11 @@ def _x(C, Ln, NP, N, g):
     return x
 
 
-@pytest.mark.parametrize("M,K,P,N", [(128, 128, 7, 700), (128, 64, 5, 257), (64, 64, 4, 1000)])
+@pytest.mark.parametrize("M,K,P,N", [(128, 128, 7, 700), (128, 64, 5, 257), (64, 64, 4, 1000), (128, 128, 40, 8200),
+                                     (64, 128, 33, 12000)])
 def test_x3_pointwise_one_source(M, K, P, N):
+    """(the last two: 1,320 / 1,551 tiles, several per persistent workgroup -- the software pipeline runs ACROSS tile
+    boundaries: epilogue stores in flight next to the ring's DMA, accumulators re-zeroed, relaxed waits)"""
     g = torch.Generator(device=DEV).manual_seed(M + K + P)
     NP = (N + 255) // 256 * 256
     W = torch.randn(M, K, generator=g, device=DEV) * 0.2
@@ -127,3 +130,54 @@ def test_x3_gru_projection_three_row_blocks():
     W = torch.randn(384, 128, generator=g, device=DEV) * 0.1
     seg = dict(x=_x(128, P, NP, N, g), mul=1, off=0, div=1, woff=0)
     _run(384, [seg], W, 128, 1, P, N, NP)
+
+
+@pytest.mark.parametrize("name,N", [("tr_k3s1", 700), ("tr_k5s2", 520), ("first_tr", 300)])
+def test_x3_fused_transposed_conv_backward_vs_fp32_mfma_kernel(name, N):
+    """convt_bwd_x3_kernel<K, S> (convt_bwd_x3.hip: weight gradient AND data gradient of ConvTranspose1d(64 -> 64) + BatchNorm
+    on the bf16 MFMA through the three-term split) against convt_bwd_kernel<K, S> on the SAME recorded forward state and
+    cotangent: the backward is linear given the state and both kernels multiply the same fp32 numbers, so every parameter
+    and input gradient of the block may differ by fp32 rounding only.  (Against float64 both are held by the block tests of
+    test_network_gpu.py, which run on the split path by default.)"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_network_gpu import BLOCKS, BLOCK_SHAPES
+    from oracle import weights as W
+    from tinyrecurrentunet_amd import _lib as L, network as hn
+    from tinyrecurrentunet_amd.engine import TRUNetEngine
+    lib = L.lib()
+    cls, args = BLOCKS[name]
+    mod = W.fill_state_dict(getattr(hn, cls)(*args), seed=13).cuda().train()
+    rng = np.random.default_rng(N)
+    xs = [torch.tensor(rng.standard_normal(s) * 0.7, dtype=torch.float32).cuda() for s in BLOCK_SHAPES[name](N)]
+    eng = TRUNetEngine(mod)
+    prev = lib.trunet_gemm_x3_enable(-1)
+    try:
+        lib.trunet_gemm_x3_enable(1)
+        y, ctx = eng.block_forward(mod._kind, getattr(mod, mod._seq), xs, True, record=True)
+        gout = torch.tensor(rng.standard_normal(tuple(y.shape)), dtype=torch.float32).cuda()
+        res = {}
+        for mode in (1, 0):
+            lib.trunet_gemm_x3_enable(mode)
+            grads, gxs = eng.block_backward(ctx, gout)
+            torch.cuda.synchronize()
+            res[mode] = ({n: grads[p].clone() for n, p in mod.named_parameters() if p in grads}, [g.clone() for g in gxs])
+    finally:
+        lib.trunet_gemm_x3_enable(prev)
+    worst = 0.0
+    assert set(res[1][0]) == set(res[0][0]) and len(res[1][0]) >= 8
+    for n, a in res[1][0].items():
+        b = res[0][0][n]
+        scale = b.norm().item()
+        if scale < 1e-4 * b.numel() ** 0.5:        # conv bias in front of a BatchNorm: analytically zero, rounding noise
+            assert a.norm().item() < 5e-2, (n, a.norm().item())
+            continue
+        e = (a - b).norm().item() / scale
+        worst = max(worst, e)
+        assert e < 2e-5, (n, e)
+    for a, b in zip(res[1][1], res[0][1]):
+        e = (a - b).norm().item() / b.norm().item()
+        worst = max(worst, e)
+        assert e < 2e-5, ("input gradient", e)
+    assert not all(torch.equal(a, res[0][0][n]) for n, a in res[1][0].items()), "the toggle changed nothing"
+    print("%s N=%d: split vs fp32-MFMA fused transposed-conv backward, worst relative L2 %.2e" % (name, N, worst))

@@ -1,30 +1,37 @@
-// Fused backward of a ConvTranspose1d(64 -> 64, k = K, stride S, padding S/2) + BatchNorm layer (autograd of
-// /root/reference/network.py:67,86 with the BatchNorm of :72,91 behind it and the BatchNorm+ReLU of :65-66,84-85 in front):
-//   z[co][p][n] = b[co] + sum_{ci,k} W[ci][co][k] a[ci][q][n],  p = q S - pad + k,   a = max(sc zs + sh, 0)
-// ONE pass over (dy, z, zs) produces
-//   dz        = ca dy + cb z + cc                                   (BatchNorm backward of z: in LDS only)
-//   dW, db    = sum_{q,n} a[ci][q] dz[co][q S - pad + k] ,  sum_{p,n} dz          (per-workgroup partial images)
-//   g         = [sc zs + sh > 0] sum_{co,k} W[ci][co][k] dz[co][q S - pad + k]   -> gradient at the source's BatchNorm output
-//   stats     = sum g, sum g (zs - mean)                            (BatchNorm backward of the source)
-// The separate launches it replaces (conv_gemm data gradient over K tap segments + conv_wgrad over K tap segments) each
-// read dy and z (the data gradient reads every dz row K/S times as a tap of different positions) and the source twice.
-//
-// Decomposition: a tile is (source position q, 32 frames).  A workgroup owns whole frame chunks and walks q = 0 .. Lin-1,
-// so the dz rows p = q S - pad .. q S - pad + K - 1 form a sliding window: every dz row is loaded and BatchNorm-transformed
-// ONCE per chunk into a ring of K + 2 S row sets and serves all K taps (positions) that need it; every step brings S new dz
-// rows (dy into the ring, z into a staging slot, combined in place by the thread that requested the piece) and one source
-// row set.  LDS-DMA (global_load_lds) two steps ahead, counted vmcnt, one barrier per step, 16-byte pieces XOR-swizzled
-// through the source address as in conv_wgrad_kernel / pw_bwd_kernel.
-//
-// All 8 waves carry the same MFMA load (16 K per step, two waves per SIMD):
-//   waves 0-3  loaders + weight gradient: wave (ci tile, co tile) keeps its K accumulators (one per tap) for the whole
-//              kernel; the frame axis is the MFMA K axis; BatchNorm+ReLU of the source is applied to the A fragment on the fly
-//   waves 4-7  data gradient: wave (ci tile, co half) keeps W^T fragments of its 32 co rows for all taps in registers;
-//              the two co halves of a ci tile are combined through LDS, and the co-half-0 wave runs the epilogue (ReLU mask,
-//              store, statistics) from registers after the barrier, in the shadow of the next step.
+// The fused ConvTranspose1d(64 -> 64) + BatchNorm backward of convt_bwd.hip with BOTH GEMMs on the bf16 MFMA through the
+// three-term operand split of gemm_x3.hip (round 4).  Same decomposition, rings, DMA schedule, prologue and epilogue as
+// convt_bwd_kernel<K, S> -- read that file's header first; what differs is how a staged fp32 fragment reaches the matrix pipe:
+//   weight gradient (waves 0-3): per 16 frames the source row's 8 values of a lane (two swizzled 16-byte pieces) get
+//       BatchNorm+ReLU and are split ONCE, every valid tap's dz row fragment is split, 6 v_mfma_f32_32x32x16_bf16 per tap;
+//   data gradient (waves 4-7): W^T of the wave's (ci tile, co half) for all taps sits in registers as three bf16 fragment
+//       planes (split once per kernel), per tap and 16 co rows the lane's 8 dz values (8 ds_read_b32) are split, 6 MFMAs.
+// Here a staged fragment feeds ONE 32-row tile per wave, so the split is not amortised (about 7 vector instructions per
+// MFMA: the waves are vector-bound) -- and still well ahead of the fp32 MFMA: 6 x 33 matrix cycles + ~45 x 4 vector cycles
+// per (32 x 32 x 16) against 8 x 64.  convt_bwd_kernel was the most matrix-bound kernel of the step (matrix pipe 62-65 %
+// busy, HBM at 0.25 of its peak).
 #include "common.hpp"
 
+#include "bf16_common.hpp"
+
 namespace {
+
+// (same split as gemm_x3.hip: terms rounded to nearest)
+__device__ __forceinline__ void ctx_split2(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+    hi = bf_pack(x0, x1);
+    const float r0 = x0 - bf_lo(hi), r1 = x1 - bf_hi(hi);
+    mid = bf_pack(r0, r1);
+    lo = bf_pack(r0 - bf_lo(mid), r1 - bf_hi(mid));
+}
+__device__ __forceinline__ void ctx_split8(const f32x4 v0, const f32x4 v1, u32x4& q0, u32x4& q1, u32x4& q2) {
+    unsigned a, b, c;
+    ctx_split2(v0[0], v0[1], a, b, c); q0[0] = a; q1[0] = b; q2[0] = c;
+    ctx_split2(v0[2], v0[3], a, b, c); q0[1] = a; q1[1] = b; q2[1] = c;
+    ctx_split2(v1[0], v1[1], a, b, c); q0[2] = a; q1[2] = b; q2[2] = c;
+    ctx_split2(v1[2], v1[3], a, b, c); q0[3] = a; q1[3] = b; q2[3] = c;
+}
+#define CTX_MF(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), acc_, 0, 0, 0)
+// six products of a three-term pair, the small cross terms first
+#define CTX_MF6(acc_, a0_, a1_, a2_, b0_, b1_, b2_) do { CTX_MF(acc_, a2_, b0_); CTX_MF(acc_, a0_, b2_); CTX_MF(acc_, a1_, b1_); CTX_MF(acc_, a1_, b0_); CTX_MF(acc_, a0_, b1_); CTX_MF(acc_, a0_, b0_); } while (0)
 
 constexpr int CT_F = 32;            // frames per tile
 constexpr int CT_C = 64;            // channels (both sides)
@@ -55,7 +62,7 @@ __device__ __forceinline__ void ct_bstore(__amdgpu_buffer_rsrc_t r, int voff, in
 __device__ __forceinline__ int ct_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 template <int K, int S>
-__global__ __launch_bounds__(512, 2) void convt_bwd_kernel(const trunet_convt_bwd_args a) {
+__global__ __launch_bounds__(512, 1) void convt_bwd_x3_kernel(const trunet_convt_bwd_args a) {
     constexpr int PAD = S / 2;
     constexpr int RDZ = K + 2 * S;      // dz ring: window + the rows of the next two steps
     constexpr int ZS = 2 * S;           // z staging slots
@@ -176,21 +183,30 @@ __global__ __launch_bounds__(512, 2) void convt_bwd_kernel(const trunet_convt_bw
                 const float* Ssrc = SRC + (q % RS) * CT_SET;
                 const int ra = cit * 32 + c, rb = cot * 32 + c;
 #pragma unroll
-                for (int qq = 0; qq < CT_F / 8; ++qq) {
-                    f32x4 av = *(const f32x4*)(Ssrc + ct_off(ra, 2 * qq + h));
+                for (int qq = 0; qq < CT_F / 16; ++qq) {
+                    // this lane's 8 frames of the K-step: 16 qq + 8 h .. + 7 = pieces 4 qq + 2 h, 4 qq + 2 h + 1 of its row
+                    f32x4 av0 = *(const f32x4*)(Ssrc + ct_off(ra, 4 * qq + 2 * h));
+                    f32x4 av1 = *(const f32x4*)(Ssrc + ct_off(ra, 4 * qq + 2 * h + 1));
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) av[e] = fmaxf(fmaf(av[e], sc_a, sh_a), 0.f);
+                    for (int e = 0; e < 4; ++e) {
+                        av0[e] = fmaxf(fmaf(av0[e], sc_a, sh_a), 0.f);
+                        av1[e] = fmaxf(fmaf(av1[e], sc_a, sh_a), 0.f);
+                    }
+                    u32x4 a0, a1, a2;
+                    ctx_split8(av0, av1, a0, a1, a2);
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
                         const int p = q * S - PAD + k;
                         if (p >= 0 && p < Lout) {
-                            const f32x4 bv = *(const f32x4*)(DZ + (p % RDZ) * CT_SET + ct_off(rb, 2 * qq + h));
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[k], 0, 0, 0);
+                            const float* Dp = DZ + (p % RDZ) * CT_SET;
+                            const f32x4 bv0 = *(const f32x4*)(Dp + ct_off(rb, 4 * qq + 2 * h));
+                            const f32x4 bv1 = *(const f32x4*)(Dp + ct_off(rb, 4 * qq + 2 * h + 1));
+                            u32x4 b0, b1, b2;
+                            ctx_split8(bv0, bv1, b0, b1, b2);
+                            CTX_MF6(acc[k], a0, a1, a2, b0, b1, b2);
                         }
                     }
-                    if (qq == 1 && q >= 1) {
+                    if (qq == 0 && q >= 1) {
                         // outstanding: rows of step q + 1 (older) and of step q + 2 (the newest n_last): transform the
                         // rows of step q + 1 in the shadow of this step's MFMAs
                         ct_wait_vmcnt(n_last);
@@ -232,13 +248,22 @@ __global__ __launch_bounds__(512, 2) void convt_bwd_kernel(const trunet_convt_bw
         const int jj = wave - 4;
         const int cit = jj & 1, chf = jj >> 1;           // ci tile, co half
         // W^T fragments: A[i = ci][k = co] per tap: af[k][kk] = W[ci = 32 cit + (lane & 31)][co = 32 chf + 2 kk + h][k]
-        float af[K][16];
+        // W^T fragment planes: lane (row ci = 32 cit + c, k = co = 32 chf + 16 ks + 8 h + j, j < 8) per tap and K-step
+        u32x4 A0[K][2], A1[K][2], A2[K][2];
         {
-            const float* wp = a.W + ((size_t)(cit * 32 + c) * CT_C + chf * 32 + h) * K;
+            const float* wp = a.W + ((size_t)(cit * 32 + c) * CT_C + chf * 32 + 8 * h) * K;
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk)
+            for (int k = 0; k < K; ++k)
 #pragma unroll
-                for (int k = 0; k < K; ++k) af[k][kk] = wp[(size_t)(2 * kk) * K + k];
+                for (int ks = 0; ks < 2; ++ks) {
+                    f32x4 w0, w1;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        w0[j] = wp[(size_t)(16 * ks + j) * K + k];
+                        w1[j] = wp[(size_t)(16 * ks + 4 + j) * K + k];
+                    }
+                    ctx_split8(w0, w1, A0[k][ks], A1[k][ks], A2[k][ks]);
+                }
         }
         float st1[16], st2[16];
 #pragma unroll
@@ -282,12 +307,21 @@ __global__ __launch_bounds__(512, 2) void convt_bwd_kernel(const trunet_convt_bw
                 for (int k = 0; k < K; ++k) {
                     const int p = q * S - PAD + k;
                     if (p >= 0 && p < Lout) {
-                        const float* Sb = DZ + (p % RDZ) * CT_SET + (chf * 32 + h) * CT_F + (c & 3);
+                        // B fragment of K-step ks: this lane's frame c, dz rows 32 chf + 16 ks + 8 h + j (j < 8); row r keeps
+                        // its 16-byte pieces XOR-swizzled by (r >> 1) & 7 = (4 h + (j >> 1)) & 7 (32 chf + 16 ks is a multiple of 16)
+                        const float* Sb = DZ + (p % RDZ) * CT_SET + (chf * 32 + 8 * h) * CT_F + (c & 3);
                         const int cpc = c >> 2;
 #pragma unroll
-                        for (int kk = 0; kk < 16; ++kk) {
-                            const float b = Sb[kk * (2 * CT_F) + 4 * (cpc ^ (kk & 7))];
-                            dacc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[k][kk], b, dacc, 0, 0, 0);
+                        for (int ks = 0; ks < 2; ++ks) {
+                            f32x4 x0, x1;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                x0[j] = Sb[(16 * ks + j) * CT_F + 4 * (cpc ^ ((4 * h + (j >> 1)) & 7))];
+                                x1[j] = Sb[(16 * ks + 4 + j) * CT_F + 4 * (cpc ^ ((4 * h + 2 + (j >> 1)) & 7))];
+                            }
+                            u32x4 b0, b1, b2;
+                            ctx_split8(x0, x1, b0, b1, b2);
+                            CTX_MF6(dacc, A0[k][ks], A1[k][ks], A2[k][ks], b0, b1, b2);
                         }
                     }
                 }
@@ -322,10 +356,10 @@ __global__ __launch_bounds__(512, 2) void convt_bwd_kernel(const trunet_convt_bw
 }
 
 template <int K, int S>
-int ct_launch(const trunet_convt_bwd_args* h, hipStream_t st) {
+int ctx_launch(const trunet_convt_bwd_args* h, hipStream_t st) {
     constexpr int RDZ = K + 2 * S, ZS = 2 * S, RS = 4;
     const size_t lds = ((size_t)(RDZ + ZS + RS) * CT_SET + 2 * 2 * 16 * 64) * sizeof(float) + 2 * CT_C * sizeof(f32x4);
-    auto kern = convt_bwd_kernel<K, S>;
+    auto kern = convt_bwd_x3_kernel<K, S>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return TRUNET_ELAUNCH;
     hipLaunchKernelGGL(kern, dim3(CT_GRID), dim3(512), lds, st, *h);
@@ -334,27 +368,10 @@ int ct_launch(const trunet_convt_bwd_args* h, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int trunet_convt_bwd_nparts(void) { return CT_GRID; }
-
-// convt_bwd_x3.hip: the same kernel with both GEMMs on the bf16 MFMA (three-term operand split, fp32-grade result);
-// taken when the split path is on (trunet_gemm_x3_enable / TRUNET_GEMM_X3, gemm_x3.hip)
-int trunet_launch_convt_bwd_x3(const trunet_convt_bwd_args* h, hipStream_t st);
-extern "C" int trunet_gemm_x3_enable(int on);
-
-extern "C" int trunet_convt_bwd(const trunet_convt_bwd_args* h, void* stream) {
-    if (!h || !h->dy || !h->z || !h->ca || !h->cb || !h->cc || !h->src || !h->s_scale || !h->s_shift || !h->s_mean ||
-        !h->W || !h->dsrc || !h->partials || !h->w_partials)
-        return TRUNET_EINVAL;
-    if (h->NP <= 0 || (h->NP % TRUNET_TILE_FRAMES) != 0 || h->N <= 0 || h->N > h->NP || h->Lin <= 0 || h->w_numel <= 0)
-        return TRUNET_EINVAL;
-    if (h->Ci != CT_C || h->Co != CT_C) return TRUNET_ENOTSUP;
-    if (h->pad != h->S / 2 || h->Lout != (h->Lin - 1) * h->S - 2 * h->pad + h->K) return TRUNET_EINVAL;
-    // 32-bit byte offsets of the buffer stores: 36 channel rows of the gradient tensor below 2 GiB
-    if ((size_t)h->Lin * h->NP * sizeof(float) * 36 >= ((size_t)1 << 31)) return TRUNET_ENOTSUP;
-    hipStream_t st = (hipStream_t)stream;
-    if (trunet_gemm_x3_enable(-1)) return trunet_launch_convt_bwd_x3(h, st);
-    if (h->K == 3 && h->S == 1) return ct_launch<3, 1>(h, st);
-    if (h->K == 3 && h->S == 2) return ct_launch<3, 2>(h, st);
-    if (h->K == 5 && h->S == 2) return ct_launch<5, 2>(h, st);
+// called by trunet_convt_bwd (convt_bwd.hip) after its argument checks when the bf16-split path is on
+int trunet_launch_convt_bwd_x3(const trunet_convt_bwd_args* h, hipStream_t st) {
+    if (h->K == 3 && h->S == 1) return ctx_launch<3, 1>(h, st);
+    if (h->K == 3 && h->S == 2) return ctx_launch<3, 2>(h, st);
+    if (h->K == 5 && h->S == 2) return ctx_launch<5, 2>(h, st);
     return TRUNET_ENOTSUP;
 }

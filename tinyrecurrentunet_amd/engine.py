@@ -973,7 +973,8 @@ class TRUNetEngine:
         a.b_stride, a.b_off = self._wg_total, 0
         if PROFILE is not None:
             fl = 4.0 * N * a.Ci * a.Co * sum(1 for q in range(a_pw.L) for kk in range(k) if 0 <= q * s_ - pad + kk < Lo)
-            with _Timed("convt_bwd_kernel<%d, %d>" % (k, s_), fl, "L%d" % a_pw.L):
+            x3 = lib.trunet_gemm_x3_enable(-1)
+            with _Timed("convt_bwd%s_kernel<%d, %d>" % ("_x3" if x3 else "", k, s_), fl, "L%d" % a_pw.L):
                 rc = lib.trunet_convt_bwd(a, L.stream())
         else:
             rc = lib.trunet_convt_bwd(a, L.stream())
