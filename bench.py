@@ -378,6 +378,28 @@ def other_configs(args, dev, step_factory):
     except Exception as e:      # context only: never take the headline line down
         out["bf16_train_step"] = {"error": repr(e)}
     try:
+        # the opt-in bf16x3 MFMA kind of the fp32 step (fp32 storage and results; not the headline: DESIGN section 3b)
+        from tinyrecurrentunet_amd import _lib as tlib
+        prev = tlib.set_fp32_mfma("bf16x3")
+        try:
+            step3, frames = step_factory("fp32")
+            for _ in range(3):
+                step3()
+            torch.cuda.synchronize()
+            t0 = time.time()
+            for _ in range(10):
+                step3()
+            torch.cuda.synchronize()
+            dt = (time.time() - t0) / 10
+        finally:
+            tlib.set_fp32_mfma(prev)
+        out["fp32_train_step_bf16x3_mfma"] = {"value": round(frames / dt, 1), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 3),
+                                               "steps": 10, "dtype": "f32", "how": "python bench.py --mfma bf16x3"}
+        del step3
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out["fp32_train_step_bf16x3_mfma"] = {"error": repr(e)}
+    try:
         a2 = copy.copy(args)
         a2.steps, a2.warmup, a2.no_cpu_baseline, a2.tgru = 200, 3, True, False
         r = streaming(a2, dev, emit=False)
@@ -408,6 +430,9 @@ def main():
                     help="initialise torch.distributed (RCCL) and the gradient all-reduce even with one rank")
     ap.add_argument("--tgru", action="store_true",
                     help="extension: TGRU block over time (use_tgru train step; with --streaming: stateful stream_step)")
+    ap.add_argument("--mfma", default="fp32", choices=["fp32", "bf16x3"],
+                    help="fp32 GEMM kernels: fp32 MFMA (default, the headline) or the opt-in three-term bf16 split on the bf16 "
+                         "MFMA (forward GEMMs + fused transposed-conv backward; fp32-grade result, DESIGN section 3b)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32: BASELINE.json configs[1] (headline); bf16: configs[2] storage/MFMA precision (extension)")
     ap.add_argument("--audio", action="store_true",
@@ -447,7 +472,8 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from tinyrecurrentunet_amd import distributed as tdist, engine, network as hn, optim, stft_loss as sl, util
+    from tinyrecurrentunet_amd import _lib as tlib, distributed as tdist, engine, network as hn, optim, stft_loss as sl, util
+    tlib.set_fp32_mfma(args.mfma)
     if args.streaming:
         return streaming_audio(args, dev) if args.audio else streaming(args, dev)
     cin = 3 if args.no_pcen else 4
@@ -605,7 +631,7 @@ def main():
                 "step_hbm_GBps_layer_model": round(value / world * HBM_BYTES_PER_FRAME_STEP / 1e9, 1)}
     extras = None
     if rank == 0 and world == 1 and not args.no_extras and args.dtype == "f32" and not (
-            args.tgru or args.no_stft_loss or args.no_pcen):
+            args.tgru or args.no_stft_loss or args.no_pcen) and args.mfma == "fp32":
         def step_factory(precision):
             torch.manual_seed(0)
             net2 = hn.TRUNet(input_size=cin, precision=precision).to(dev).train()
@@ -634,6 +660,7 @@ def main():
                                           "bf16-storage (bf16 MFMA, fp32 accumulate / statistics / master weights)",
                                           ("" if stft_lambda else " WITHOUT MR-STFT loss") +
                                           (" WITH the TGRU block trained over time (use_tgru extension)" if args.tgru else "")),
+                          "fp32_mfma": tlib.fp32_mfma() if args.dtype == "f32" else None,
                           "frames_per_gpu": frames, "global_batch": args.batch * world,
                           "parallelism": "dp%d" % world, "loss": float(loss.detach())},
                "roofline": roof, "cpu_baseline": cpu}

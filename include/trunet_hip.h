@@ -96,12 +96,14 @@ typedef struct {
 /* number of partial rows a trunet_conv_gemm launch writes (so the caller can size `partials`) */
 int trunet_conv_gemm_nparts(int M);
 int trunet_conv_gemm(const trunet_gemm_args* h_args, void* stream);
-/* Launches of trunet_conv_gemm without a tensor-operand epilogue (no TRUNET_EPI_MASK / ACCUM: the forward pass), a one-tensor
- * prologue, M = 64 or a multiple of 128 and NP a multiple of 256 run on conv_gemm_x3_kernel (gemm_x3.hip): fp32 operands split
- * EXACTLY into three bf16 terms, six v_mfma_f32_32x32x16_bf16 per 16 K-values with fp32 accumulation -- the 24 significant
- * bits per product of an fp32 FMA chain at 6/16 of the fp32-MFMA time.  trunet_gemm_x3_enable(0 / 1) switches the path off /
- * on for the process (A/B measurements and tests), (-1) only queries; returns the previous setting.  Environment default:
- * TRUNET_GEMM_X3 (unset = on). */
+/* OPT-IN (default off; round 4): with trunet_gemm_x3_enable(1) -- or TRUNET_GEMM_X3=1 in the environment -- the launches of
+ * trunet_conv_gemm without a tensor-operand epilogue (no TRUNET_EPI_MASK / ACCUM: the forward pass; one-tensor prologue,
+ * M = 64 or a multiple of 128, NP a multiple of 256) run on conv_gemm_x3_kernel (gemm_x3.hip) and trunet_convt_bwd on
+ * convt_bwd_x3_kernel (convt_bwd_x3.hip): fp32 operands split into three bf16 terms (24 significand bits), six
+ * v_mfma_f32_32x32x16_bf16 per 16 K-values with fp32 accumulation -- an fp32-grade result (error against float64 equal to
+ * the fp32-MFMA kernels', tests/test_gemm_x3_gpu.py) at 6/16 of the fp32-MFMA time, but with a rounding pattern that is
+ * uncorrelated with a sequential fp32 FMA chain (why it is not the default).  (0) switches it off, (-1)
+ * only queries; returns the previous setting. */
 int trunet_gemm_x3_enable(int on);
 /* launch geometry trunet_conv_gemm picks for these arguments (reporting): kernel instance
  * conv_gemm_kernel<rs, kc, two, epl, nw> (or conv_smallm_kernel<epl> when M <= 8 and !two), ring of nb LDS slots;

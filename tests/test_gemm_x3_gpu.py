@@ -181,3 +181,104 @@ def test_x3_fused_transposed_conv_backward_vs_fp32_mfma_kernel(name, N):
         assert e < 2e-5, ("input gradient", e)
     assert not all(torch.equal(a, res[0][0][n]) for n, a in res[1][0].items()), "the toggle changed nothing"
     print("%s N=%d: split vs fp32-MFMA fused transposed-conv backward, worst relative L2 %.2e" % (name, N, worst))
+
+
+# ---------------------------------------------------------------- the opt-in path through the network (fp32 MFMA kind "bf16x3")
+@pytest.fixture
+def bf16x3():
+    from tinyrecurrentunet_amd import _lib
+    prev = _lib.set_fp32_mfma("bf16x3")
+    yield
+    _lib.set_fp32_mfma(prev)
+
+
+@pytest.mark.parametrize("cin", [3, 4])
+def test_bf16x3_network_forward_and_backward_match_reference_goldens(golden, cin, bf16x3):
+    """With the split kernels on, the goldens of the reference composition hold unchanged: y_eval (layer-by-layer path)
+    and y_train at 1e-4, every parameter gradient within the whole-network bounds of test_network_gpu._grad_close."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_network_gpu import _grad_close, _nets, _rel
+    from tinyrecurrentunet_amd import _lib
+    assert _lib.fp32_mfma() == "bf16x3"
+    g = golden("trunet_cin%d" % cin)
+    _, net = _nets(cin, seed=0)
+    x = torch.tensor(g["x"]).cuda()
+    net.eval()
+    net.fold_eval = False
+    with torch.no_grad():
+        assert _rel(net(x), torch.tensor(g["y_eval"])) < 1e-4
+    net.train()
+    y = net(x)
+    assert _rel(y, torch.tensor(g["y_train"])) < 1e-4
+    (y * torch.tensor(g["cot"]).cuda()).sum().backward()
+    for pn, p in net.named_parameters():
+        if pn.startswith("TGRU"):
+            continue
+        _grad_close(p.grad, torch.tensor(g["g:" + pn]), pn)
+
+
+def test_bf16x3_forward_vs_float64_and_vs_the_fp32_mfma_path(bf16x3):
+    """Training-mode forward at a ragged frame count against the float64 oracle (1e-4 like the default path) and the
+    parameter gradients of both fp32 paths against float64: the split path must not be further from the truth than the
+    fp32-MFMA path (x 1.5 + the bounds' own noise floor)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from oracle import network_ref as nr, weights as W
+    from test_network_gpu import _nets, _rel
+    from tinyrecurrentunet_amd import _lib
+    N = 777
+    _, net = _nets(4, seed=3)
+    refd = W.fill_state_dict(nr.TRUNet(input_size=4), seed=3).double().train()
+    x = torch.tensor(np.random.default_rng(N).standard_normal((N, 4, 257)) * 0.5, dtype=torch.float32)
+    cot = torch.tensor(np.random.default_rng(N + 1).standard_normal((N, 8, 257)), dtype=torch.float32)
+    yd = refd(x.double())
+    (yd * cot.double()).sum().backward()
+    pd = dict(refd.named_parameters())
+    med = {}
+    for kind in ("bf16x3", "fp32"):
+        _lib.set_fp32_mfma(kind)
+        net.zero_grad(set_to_none=True)
+        net.train()
+        y = net(x.cuda())
+        assert _rel(y, yd) < 1e-4, (kind, _rel(y, yd))
+        (y * cot.cuda()).sum().backward()
+        es = []
+        for pn, p in net.named_parameters():
+            if pn.startswith("TGRU") or float(pd[pn].grad.abs().max()) < 1e-3:
+                continue
+            es.append(float((p.grad.double().cpu() - pd[pn].grad).norm() / pd[pn].grad.norm()))
+        med[kind] = (float(np.median(es)), max(es))
+    print("N = %d gradients vs float64: split median %.2e max %.2e; fp32-MFMA median %.2e max %.2e" % (
+        (N,) + med["bf16x3"] + med["fp32"]))
+    assert med["bf16x3"][0] < 1.5 * med["fp32"][0] + 5e-3 and med["bf16x3"][1] < 1.5 * med["fp32"][1] + 2e-2, med
+
+
+def test_bf16x3_full_size_forward_agrees_with_the_fp32_mfma_path(bf16x3):
+    """N = 32,064 (the benchmarked size; the fp32-MFMA forward at this size is pinned to the oracle at 1e-4 by
+    test_configs_gpu.test_cfg2_*): every stored layer output of the split path within 1e-5 relative L2 and 3e-5 of max|z|
+    of the fp32-MFMA path, the BatchNorm coefficients within 1e-6."""
+    from tinyrecurrentunet_amd import _lib, network as hn
+    from tinyrecurrentunet_amd.engine import TRUNetEngine
+    torch.manual_seed(0)
+    net = hn.TRUNet(input_size=4).cuda().train()
+    N = 32064
+    x = torch.randn(N, 4, 257, device="cuda") * 0.5
+    res = {}
+    for kind in ("fp32", "bf16x3"):
+        _lib.set_fp32_mfma(kind)
+        eng = TRUNetEngine(net)
+        out, (acts, _, NP, w, _) = eng.forward(x, True, record=True)
+        res[kind] = {k: (a.t[:, :, :N].clone(), None if a.bn is None else a.bn.scale.clone()) for k, a in acts.items()
+                     if hasattr(a, "t")}
+        del eng, acts, w
+        torch.cuda.empty_cache()
+    worst = 0.0
+    for k, (b, sb) in res["fp32"].items():
+        a, sa = res["bf16x3"][k]
+        e = ((a - b).norm() / b.norm()).item()
+        worst = max(worst, e)
+        assert e < 1e-5 and ((a - b).abs().max() / b.abs().max()).item() < 3e-5, (k, e)
+        if sb is not None:
+            assert ((sa - sb).norm() / sb.norm()).item() < 1e-6, k
+    print("full-size forward, split vs fp32-MFMA: worst layer relative L2 %.2e" % worst)

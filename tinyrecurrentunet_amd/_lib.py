@@ -240,6 +240,21 @@ def declared_symbols():
     return list(lib()._declared)
 
 
+def set_fp32_mfma(kind):
+    """"fp32" (default): every fp32 GEMM kernel multiplies on v_mfma_f32_32x32x2_f32.  "bf16x3" (opt-in, round 4): the
+    forward implicit GEMMs and the fused transposed-conv backward split their fp32 operands into three bf16 terms and
+    multiply on the bf16 MFMA with fp32 accumulation (gemm_x3.hip, convt_bwd_x3.hip): same accuracy against float64,
+    different rounding pattern, ~5 % shorter fp32 step.  Process-wide; returns the previous kind."""
+    if kind not in ("fp32", "bf16x3"):
+        raise ValueError("fp32 MFMA kind must be 'fp32' or 'bf16x3', got %r" % (kind,))
+    prev = lib().trunet_gemm_x3_enable(1 if kind == "bf16x3" else 0)
+    return "bf16x3" if prev else "fp32"
+
+
+def fp32_mfma():
+    return "bf16x3" if lib().trunet_gemm_x3_enable(-1) else "fp32"
+
+
 def check(rc, what=""):
     if rc != 0:
         raise TrunetHipError("libtrunet_hip call failed (%s): code %d" % (what, rc))

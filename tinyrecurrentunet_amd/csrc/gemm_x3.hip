@@ -340,10 +340,10 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_kernel(const trunet_gemm_
 }  // namespace
 
 // 0 = not eligible (the caller launches conv_gemm_kernel), else NRT.  *nb / *lds: ring slots and LDS bytes.
-static int g_x3_on = -1;       // -1: not decided yet (environment TRUNET_GEMM_X3, default on)
+static int g_x3_on = -1;       // -1: not decided yet (environment TRUNET_GEMM_X3 = 1 switches it on; default OFF)
 
 extern "C" int trunet_gemm_x3_enable(int on) {
-    const int prev = g_x3_on < 0 ? !(getenv("TRUNET_GEMM_X3") && getenv("TRUNET_GEMM_X3")[0] == '0') : g_x3_on;
+    const int prev = g_x3_on < 0 ? ((getenv("TRUNET_GEMM_X3") && getenv("TRUNET_GEMM_X3")[0] == '1') ? 1 : 0) : g_x3_on;
     if (on >= 0) g_x3_on = on ? 1 : 0;
     return prev;
 }
