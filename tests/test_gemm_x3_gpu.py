@@ -282,3 +282,66 @@ def test_bf16x3_full_size_forward_agrees_with_the_fp32_mfma_path(bf16x3):
         if sb is not None:
             assert ((sa - sb).norm() / sb.norm()).item() < 1e-6, k
     print("full-size forward, split vs fp32-MFMA: worst layer relative L2 %.2e" % worst)
+
+
+def test_bf16x3_full_size_gradients_vs_oracle_away_from_the_clamp_edges(bf16x3):
+    """The full configs[1] step (64 x 4 s, N = 32,064) on the split path against the fp32 oracle's backward -- the bounds of
+    test_configs_gpu.test_cfg2_full_size_train_step_vs_oracle (median 6e-3, max 3e-2 over the tensors) -- with ONE
+    difference: the gradient of the loss is not propagated through the ~1e-4 of the network's magnitude-channel outputs that lie
+    within 1e-4 of the clamp edges |o0| = 1 of R7 (dataset.py:229-235's norm range).  There d loss / d o0 switches between
+    0 and a value ~1000x the typical element (amplitude 10^1.25), and on which side an output falls is decided by the
+    sixth digit: profiles/round4_x3_loss_sensitivity.txt -- at B = 64 ten such elements carry 99 % of the squared
+    difference between the loss gradients of the two fp32 paths, whose outputs agree to 2e-6 (and each agrees with
+    float64 to 1.7-1.8e-6, profiles/round4_x3_vs_float64.txt).  With those elements taken out of BOTH backward passes the
+    split path meets the unchanged bounds."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from oracle import loss_ref, network_ref as nr, weights as W
+    from test_network_gpu import _grad_close
+    from tinyrecurrentunet_amd import _lib, dataset as ds, network as hn, stft_loss as sl, util
+    CFG = dict(fft_sizes=[512, 1024, 2048], hop_sizes=[50, 120, 240], win_lengths=[240, 600, 1200], sc_lambda=0.5,
+               mag_lambda=0.5, band="full")
+    B, L = 64, 64000
+    clean, noisy = W.synth_pairs(B, L, seed=1234)
+    ref = W.fill_state_dict(nr.TRUNet(input_size=4), seed=0)
+    net = hn.TRUNet(input_size=4)
+    net.load_state_dict(ref.state_dict())
+    net.cuda().train()
+    mr = sl.MultiResolutionSTFTLoss(**CFG).cuda()
+    cg, ng = clean.cuda(), noisy.cuda()
+    with torch.no_grad():
+        y = net(ds.stft_features(ng[:, 0].contiguous(), pcen=True))
+    keep = torch.ones_like(y)
+    edge = (y[:, 0].abs() - 1.0).abs() < 1e-4
+    keep[:, 0][edge] = 0.0
+    n_edge = int(edge.sum())
+    assert 0 < n_edge < 1e-3 * edge.numel(), n_edge
+    net.load_state_dict(ref.state_dict())
+    h1 = net.register_forward_hook(lambda m, i, o: (o.register_hook(lambda g: g * keep), None)[1] if o.requires_grad else None)
+    loss, info = util.loss_fn(net, (cg, ng), ell_p=1, ell_p_lambda=1, stft_lambda=1, mrstftloss=mr)
+    loss.backward()
+    h1.remove()
+    torch.cuda.synchronize()
+    g1 = {n: p.grad.clone().cpu() for n, p in net.named_parameters() if p.grad is not None}
+    assert _lib.fp32_mfma() == "bf16x3"
+    keep_h = keep.cpu()
+    del net, y, keep
+    torch.cuda.empty_cache()
+    ref.train()
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    h2 = ref.register_forward_hook(lambda m, i, o: (o.register_hook(lambda g: g * keep_h), None)[1] if o.requires_grad else None)
+    loss_o, info_o, _ = loss_ref.loss_fn(ref, clean, noisy, stft_config=CFG, pcen=True)
+    loss_o.backward()
+    h2.remove()
+    assert abs(float(loss) - float(loss_o)) < 1e-4 * abs(float(loss_o))
+    errs = []
+    pd = dict(ref.named_parameters())
+    for pn, g in g1.items():
+        _grad_close(g, pd[pn].grad, pn, errs)
+    msg = "full-size split path vs the fp32 oracle, %d clamp-edge outputs excluded: relative L2 median %.2e max %.2e over %d tensors" % (
+        n_edge, float(np.median(errs)), max(errs), len(errs))
+    print(msg)
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out")
+    if os.path.isdir(out_dir):
+        open(os.path.join(out_dir, "parity_fullsize_x3.txt"), "a").write(msg + "\n")
+    assert float(np.median(errs)) < 6e-3 and max(errs) < 3e-2, msg
