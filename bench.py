@@ -75,6 +75,7 @@ FLOPS_PER_FRAME_STEP = 94089216       # 3 x 31,363,072 (C_in = 4)
 PEAK_F32_TFLOPS = 157.3               # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
 HBM_BYTES_PER_FRAME_STEP = 2462912    # SURVEY 8d (ii) layer-boundary model
 PEAK_HBM_GBPS = 8000.0                # MI355X_MICROARCH.md: HBM3E
+PEAK_BF16_TFLOPS = 2500.0             # MI355X_MICROARCH.md: dense bf16 MFMA
 
 
 def spawn_ranks(n):
@@ -377,28 +378,30 @@ def other_configs(args, dev, step_factory):
         torch.cuda.empty_cache()
     except Exception as e:      # context only: never take the headline line down
         out["bf16_train_step"] = {"error": repr(e)}
-    try:
-        # the opt-in bf16x3 MFMA kind of the fp32 step (fp32 storage and results; not the headline: DESIGN section 3b)
-        from tinyrecurrentunet_amd import _lib as tlib
-        prev = tlib.set_fp32_mfma("bf16x3")
+    # the other MFMA kinds of the fp32 step (fp32 storage and results in every case): all fp32 MFMA (the
+    # headline path until round 3) and the opt-in split in the forward GEMMs as well
+    from tinyrecurrentunet_amd import _lib as tlib
+    for kind, key in (("fp32", "fp32_train_step_fp32_mfma"), ("bf16x3", "fp32_train_step_bf16x3_mfma")):
         try:
-            step3, frames = step_factory("fp32")
-            for _ in range(3):
-                step3()
-            torch.cuda.synchronize()
-            t0 = time.time()
-            for _ in range(10):
-                step3()
-            torch.cuda.synchronize()
-            dt = (time.time() - t0) / 10
-        finally:
-            tlib.set_fp32_mfma(prev)
-        out["fp32_train_step_bf16x3_mfma"] = {"value": round(frames / dt, 1), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 3),
-                                               "steps": 10, "dtype": "f32", "how": "python bench.py --mfma bf16x3"}
-        del step3
-        torch.cuda.empty_cache()
-    except Exception as e:
-        out["fp32_train_step_bf16x3_mfma"] = {"error": repr(e)}
+            prev = tlib.set_fp32_mfma(kind)
+            try:
+                step3, frames = step_factory("fp32")
+                for _ in range(3):
+                    step3()
+                torch.cuda.synchronize()
+                t0 = time.time()
+                for _ in range(10):
+                    step3()
+                torch.cuda.synchronize()
+                dt = (time.time() - t0) / 10
+            finally:
+                tlib.set_fp32_mfma(prev)
+            out[key] = {"value": round(frames / dt, 1), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 3),
+                        "steps": 10, "dtype": "f32", "how": "python bench.py --mfma %s" % kind}
+            del step3
+            torch.cuda.empty_cache()
+        except Exception as e:
+            out[key] = {"error": repr(e)}
     try:
         a2 = copy.copy(args)
         a2.steps, a2.warmup, a2.no_cpu_baseline, a2.tgru = 200, 3, True, False
@@ -430,9 +433,11 @@ def main():
                     help="initialise torch.distributed (RCCL) and the gradient all-reduce even with one rank")
     ap.add_argument("--tgru", action="store_true",
                     help="extension: TGRU block over time (use_tgru train step; with --streaming: stateful stream_step)")
-    ap.add_argument("--mfma", default="fp32", choices=["fp32", "bf16x3"],
-                    help="fp32 GEMM kernels: fp32 MFMA (default, the headline) or the opt-in three-term bf16 split on the bf16 "
-                         "MFMA (forward GEMMs + fused transposed-conv backward; fp32-grade result, DESIGN section 3b)")
+    ap.add_argument("--mfma", default="bf16x3-bwd", choices=["fp32", "bf16x3-bwd", "bf16x3"],
+                    help="matrix instruction of the fp32 GEMM kernels (fp32 storage, accumulation and results in every case): "
+                         "bf16x3-bwd (default) = fp32 MFMA in the forward pass, three-term bf16 split on the bf16 MFMA in the fused "
+                         "backward kernels (forward, loss and loss gradient bit-identical to fp32; every fp32 parity gate "
+                         "unchanged); fp32 = fp32 MFMA everywhere; bf16x3 = the split in the forward GEMMs too (opt-in, DESIGN 3b)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32: BASELINE.json configs[1] (headline); bf16: configs[2] storage/MFMA precision (extension)")
     ap.add_argument("--audio", action="store_true",
@@ -548,6 +553,7 @@ def main():
     # the step (it contains the gradient all-reduce); only rank 0 instruments it.
     if rank == 0:
         engine.PROFILE = prof = {}
+        engine.PROFILE_BYTES.clear()
         if os.environ.get("TRUNET_BENCH_LAUNCH_LOG"):
             engine.PROFILE_LOG = []
     bucket = getattr(net, "_grad_bucket", None)
@@ -617,6 +623,28 @@ def main():
                     "kernel_ms_per_step": {k: round(v[0], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])},
                     "step_hbm_GBps_layer_model": round(value / world * bytes_per_frame / 1e9, 1),
                     "step_hbm_frac_layer_model": round(value / world * bytes_per_frame / 1e9 / PEAK_HBM_GBPS, 4)}
+        elif name.startswith("pw_bwd_kernel") and name.endswith(", true>") and engine.PROFILE_BYTES.get(name):
+            # the fused pointwise backward with both GEMMs on the bf16 MFMA (three-term split): one fp32 multiply-add is six
+            # bf16 ones, so the matrix pipe sits at 6 x (fp32-equivalent rate) / 2.5 PF -- and the HBM stream is the nearer
+            # roof: ALGORITHMIC bytes (dy, z_y, sources read once; gradients written once) over the launch time
+            nbytes = engine.PROFILE_BYTES[name]
+            gbs = nbytes / (tot_ms * 1e-3) / 1e9
+            mfma_frac = 6.0 * ach / PEAK_BF16_TFLOPS
+            roof = {"bound": "hbm" if gbs / PEAK_HBM_GBPS >= mfma_frac else "mfma", "kernel": name,
+                    "achieved": round(gbs, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBPS, 4),
+                    "traffic": traffic, "traffic_GBps": (round(traffic / (tot_ms / n * 1e-3) / 1e9, 1) if traffic else None),
+                    "traffic_source": traffic_src, "traffic_measured_on_other_kernel_source": traffic_stale,
+                    "launches_per_step": n, "avg_launch_ms": round(tot_ms / n, 4),
+                    "algorithmic_bytes_per_launch": round(nbytes / n),
+                    "fp32_equivalent_TFLOPs": round(ach, 2), "bf16_mfma_TFLOPs": round(6.0 * ach, 1),
+                    "bf16_mfma_frac_of_peak": round(mfma_frac, 4),
+                    "fp32_mfma_peak_TFLOPs_for_reference": PEAK_F32_TFLOPS,
+                    "kernel_ms_per_step": {k: round(v[0], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])},
+                    "step_hbm_GBps_layer_model": round(value / world * HBM_BYTES_PER_FRAME_STEP / 1e9, 1),
+                    "step_hbm_frac_layer_model": round(value / world * HBM_BYTES_PER_FRAME_STEP / 1e9 / PEAK_HBM_GBPS, 4)}
+            if roof["bound"] == "mfma":
+                roof.update({"achieved": round(6.0 * ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(mfma_frac, 4),
+                             "hbm_GBps": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM_GBPS, 4)})
         else:
           roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": traffic,
@@ -631,7 +659,7 @@ def main():
                 "step_hbm_GBps_layer_model": round(value / world * HBM_BYTES_PER_FRAME_STEP / 1e9, 1)}
     extras = None
     if rank == 0 and world == 1 and not args.no_extras and args.dtype == "f32" and not (
-            args.tgru or args.no_stft_loss or args.no_pcen) and args.mfma == "fp32":
+            args.tgru or args.no_stft_loss or args.no_pcen) and args.mfma == "bf16x3-bwd":
         def step_factory(precision):
             torch.manual_seed(0)
             net2 = hn.TRUNet(input_size=cin, precision=precision).to(dev).train()
@@ -660,6 +688,8 @@ def main():
                                           "bf16-storage (bf16 MFMA, fp32 accumulate / statistics / master weights)",
                                           ("" if stft_lambda else " WITHOUT MR-STFT loss") +
                                           (" WITH the TGRU block trained over time (use_tgru extension)" if args.tgru else "")),
+                          "mfma": ({"fp32": "fp32", "bf16x3-bwd": "fp32 forward, bf16x3 backward", "bf16x3": "bf16x3"}[tlib.fp32_mfma()]
+                                   if args.dtype == "f32" else "bf16"),
                           "fp32_mfma": tlib.fp32_mfma() if args.dtype == "f32" else None,
                           "frames_per_gpu": frames, "global_batch": args.batch * world,
                           "parallelism": "dp%d" % world, "loss": float(loss.detach())},

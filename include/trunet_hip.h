@@ -96,14 +96,22 @@ typedef struct {
 /* number of partial rows a trunet_conv_gemm launch writes (so the caller can size `partials`) */
 int trunet_conv_gemm_nparts(int M);
 int trunet_conv_gemm(const trunet_gemm_args* h_args, void* stream);
-/* OPT-IN (default off; round 4): with trunet_gemm_x3_enable(1) -- or TRUNET_GEMM_X3=1 in the environment -- the launches of
- * trunet_conv_gemm without a tensor-operand epilogue (no TRUNET_EPI_MASK / ACCUM: the forward pass; one-tensor prologue,
- * M = 64 or a multiple of 128, NP a multiple of 256) run on conv_gemm_x3_kernel (gemm_x3.hip) and trunet_convt_bwd on
- * convt_bwd_x3_kernel (convt_bwd_x3.hip): fp32 operands split into three bf16 terms (24 significand bits), six
+/* The fp32 GEMMs on the bf16 matrix pipe (round 4): fp32 operands split into three bf16 terms (24 significand bits), six
  * v_mfma_f32_32x32x16_bf16 per 16 K-values with fp32 accumulation -- an fp32-grade result (error against float64 equal to
- * the fp32-MFMA kernels', tests/test_gemm_x3_gpu.py) at 6/16 of the fp32-MFMA time, but with a rounding pattern that is
- * uncorrelated with a sequential fp32 FMA chain (why it is not the default).  (0) switches it off, (-1)
- * only queries; returns the previous setting. */
+ * the fp32-MFMA kernels', tests/test_gemm_x3_gpu.py) at 6/16 of the fp32-MFMA time.  trunet_gemm_x3_enable(mask) selects
+ * where (returns the previous mask; -1 only queries; environment TRUNET_GEMM_X3 = 0..3 sets the initial value):
+ *   TRUNET_X3_BWD  (default ON)  the fused backward kernels trunet_pw_bwd (pw_bwd.hip) and trunet_convt_bwd
+ *                  (convt_bwd_x3.hip).  Backward is a linear map of the saved forward state: the forward pass, the loss and
+ *                  the loss gradient stay bit for bit those of the fp32-MFMA path, the parameter gradients move at the 1e-7
+ *                  level, and every parity gate of the fp32 path holds unchanged.
+ *   TRUNET_X3_GEMM (default OFF) the launches of trunet_conv_gemm without a tensor-operand epilogue (no TRUNET_EPI_MASK /
+ *                  ACCUM: the forward pass; one-tensor prologue, M = 64 or a multiple of 128, NP a multiple of 256) on
+ *                  conv_gemm_x3_kernel (gemm_x3.hip).  Equally accurate, but the rounding pattern of the OUTPUT is then
+ *                  uncorrelated with a sequential fp32 FMA chain, and the loss gradient of this network is ill conditioned
+ *                  in a handful of output elements: at the benchmarked size the full-size gradient gate against the fp32
+ *                  oracle does not hold, so it stays opt-in. */
+#define TRUNET_X3_GEMM 1
+#define TRUNET_X3_BWD 2
 int trunet_gemm_x3_enable(int on);
 /* launch geometry trunet_conv_gemm picks for these arguments (reporting): kernel instance
  * conv_gemm_kernel<rs, kc, two, epl, nw> (or conv_smallm_kernel<epl> when M <= 8 and !two), ring of nb LDS slots;

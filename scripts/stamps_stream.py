@@ -13,13 +13,20 @@ sys.path.insert(0, ROOT)
 from tinyrecurrentunet_amd import export, network as hn  # noqa: E402
 
 lib = C.CDLL(os.path.join(ROOT, "scripts", "dbg", os.environ.get("SF_LIB", "libsf_stamps.so")))
-lib.trunet_stream_fwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.c_int,
-                                  C.c_int, C.c_void_p]
+lib.trunet_stream_fwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.c_int64, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
 lib.trunet_stream_fwd_scratch_floats.restype = C.c_size_t
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 torch.manual_seed(0)
 net = hn.TRUNet(input_size=4).cuda().eval()
 f = export.FoldedTRUNet.from_module(net)
+NO, BN = len(f.offsets), f.blob.numel()
+
+
+def launch():
+    return lib.trunet_stream_fwd(x.data_ptr(), y.data_ptr(), f.blob.data_ptr(), f._offs, NO, BN, scratch.data_ptr(), None, None, N,
+                                 4, st)
+
 x = torch.randn(N, 4, 257, device="cuda")
 y = torch.empty(N, 8, 257, device="cuda")
 grid = lib.trunet_stream_fwd_grid(N)
@@ -27,11 +34,11 @@ nf = lib.trunet_stream_fwd_scratch_floats(grid)
 scratch = torch.zeros(nf, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
 for _ in range(3):
-    assert lib.trunet_stream_fwd(x.data_ptr(), y.data_ptr(), f.blob.data_ptr(), f._offs, 26, scratch.data_ptr(), N, 4, st) == 0
+    assert launch() == 0
 torch.cuda.synchronize()
 t0 = time.time()
 for _ in range(20):
-    lib.trunet_stream_fwd(x.data_ptr(), y.data_ptr(), f.blob.data_ptr(), f._offs, 26, scratch.data_ptr(), N, 4, st)
+    launch()
 torch.cuda.synchronize()
 dt = (time.time() - t0) / 20
 s = scratch[grid * 45056:].view(torch.int64)[:64].cpu().numpy().astype(np.int64)

@@ -240,19 +240,27 @@ def declared_symbols():
     return list(lib()._declared)
 
 
+X3_GEMM, X3_BWD = 1, 2                   # trunet_hip.h: TRUNET_X3_GEMM, TRUNET_X3_BWD
+_MFMA_KINDS = {"fp32": 0, "bf16x3-bwd": X3_BWD, "bf16x3-fwd": X3_GEMM, "bf16x3": X3_GEMM | X3_BWD}
+
+
 def set_fp32_mfma(kind):
-    """"fp32" (default): every fp32 GEMM kernel multiplies on v_mfma_f32_32x32x2_f32.  "bf16x3" (opt-in, round 4): the
-    forward implicit GEMMs and the fused transposed-conv backward split their fp32 operands into three bf16 terms and
-    multiply on the bf16 MFMA with fp32 accumulation (gemm_x3.hip, convt_bwd_x3.hip): same accuracy against float64,
-    different rounding pattern, ~5 % shorter fp32 step.  Process-wide; returns the previous kind."""
-    if kind not in ("fp32", "bf16x3"):
-        raise ValueError("fp32 MFMA kind must be 'fp32' or 'bf16x3', got %r" % (kind,))
-    prev = lib().trunet_gemm_x3_enable(1 if kind == "bf16x3" else 0)
-    return "bf16x3" if prev else "fp32"
+    """Which matrix instruction the fp32 GEMM kernels multiply on (storage, accumulation and results are fp32 in every case).
+    "fp32": v_mfma_f32_32x32x2_f32 everywhere.  "bf16x3-bwd" (the default since round 4): the fused backward kernels
+    (pw_bwd.hip, convt_bwd_x3.hip) split their fp32 operands into three bf16 terms and multiply on the bf16 MFMA -- backward
+    is linear in the saved forward state, so the forward pass, the loss and the loss gradient are bit for bit those of
+    "fp32" and the parameter gradients move at the 1e-7 level.  "bf16x3" (opt-in): the forward implicit GEMMs as well
+    (gemm_x3.hip): same accuracy against float64, different rounding pattern of the network output.
+    Process-wide; returns the previous kind."""
+    if kind not in _MFMA_KINDS:
+        raise ValueError("fp32 MFMA kind must be one of %s, got %r" % (sorted(_MFMA_KINDS), kind))
+    prev = lib().trunet_gemm_x3_enable(_MFMA_KINDS[kind])
+    return [k for k, v in _MFMA_KINDS.items() if v == prev][0]
 
 
 def fp32_mfma():
-    return "bf16x3" if lib().trunet_gemm_x3_enable(-1) else "fp32"
+    m = lib().trunet_gemm_x3_enable(-1)
+    return [k for k, v in _MFMA_KINDS.items() if v == m][0]
 
 
 def check(rc, what=""):

@@ -340,16 +340,20 @@ __global__ __launch_bounds__(512, 1) void conv_gemm_x3_kernel(const trunet_gemm_
 }  // namespace
 
 // 0 = not eligible (the caller launches conv_gemm_kernel), else NRT.  *nb / *lds: ring slots and LDS bytes.
-static int g_x3_on = -1;       // -1: not decided yet (environment TRUNET_GEMM_X3 = 1 switches it on; default OFF)
+static int g_x3_on = -1;       // -1: not decided yet.  Bit mask: TRUNET_X3_GEMM (1) | TRUNET_X3_BWD (2); default TRUNET_X3_BWD
 
 extern "C" int trunet_gemm_x3_enable(int on) {
-    const int prev = g_x3_on < 0 ? ((getenv("TRUNET_GEMM_X3") && getenv("TRUNET_GEMM_X3")[0] == '1') ? 1 : 0) : g_x3_on;
-    if (on >= 0) g_x3_on = on ? 1 : 0;
+    if (g_x3_on < 0) {
+        const char* e = getenv("TRUNET_GEMM_X3");
+        g_x3_on = (e && e[0] >= '0' && e[0] <= '3' && !e[1]) ? e[0] - '0' : TRUNET_X3_BWD;
+    }
+    const int prev = g_x3_on;
+    if (on >= 0) g_x3_on = on & (TRUNET_X3_GEMM | TRUNET_X3_BWD);
     return prev;
 }
 
 int trunet_gemm_x3_plan(const trunet_gemm_args* h, int* nb, size_t* lds) {
-    if (!trunet_gemm_x3_enable(-1)) return 0;
+    if (!(trunet_gemm_x3_enable(-1) & TRUNET_X3_GEMM)) return 0;
     if (h->epi & (TRUNET_EPI_MASK | TRUNET_EPI_ACCUM)) return 0;
     if ((h->NP % X3_FT) != 0) return 0;
     int nrt;

@@ -25,9 +25,18 @@
 //     sources for the whole kernel (plus, with six row tiles, a second one on alternate tiles), keeps the matching
 //     W^T fragments in registers, and runs the epilogue (accumulate / ReLU mask / statistics / store) itself.
 // The two roles execute different loops with the same barrier sequence.
+//
+// X3 (round 4; the default, trunet_gemm_x3_enable & TRUNET_X3_BWD): both GEMMs on v_mfma_f32_32x32x16_bf16 through the
+// three-term operand split of x3_common.hpp.  Nothing else changes -- ring, DMA schedule, prologue pass, epilogue --: a lane
+// reads the 8 consecutive K-values of its fragment from the fp32 slot (weight gradient: two swizzled 16-byte pieces of a
+// row, K = frames; data gradient: 8 ds_read_b32 down the dz rows, K = rows), splits them (~44 vector instructions) and
+// issues 6 MFMAs; the data-gradient waves keep W^T as three pre-split fragment planes.  Per (32 x 32 x 16): 6 x 33 matrix
+// cycles next to ~45 x 4 vector cycles instead of 8 x 64 matrix cycles -- fp32 MFMA runs at the vector rate on this chip
+// and was what bounded these kernels (matrix pipe 67 % busy at 0.55 of the HBM rate).
 #include <cstdlib>
 #include <type_traits>
 #include "common.hpp"
+#include "x3_common.hpp"
 
 #ifndef PWB_ABL      // diagnostic builds only (scripts/ubench_pwbwd.py): 1 no epilogue loads, 2 no epilogue stores,
 #define PWB_ABL 0    // 4 no prologue pass, 8 no DMA refill, 16 no weight-gradient MFMAs, 32 no data-gradient MFMAs
@@ -135,7 +144,7 @@ struct DRun {
 // keeps).  Without it two waves alternated whole tiles: the active wave carried AK MFMAs next to its SIMD partner's
 // weight-gradient MFMAs while the other pair of SIMDs idled, 96 instead of 64 MFMA times per tile (measured 60 TF against
 // 85 TF for the four-row-tile layers).
-template <int AK, bool SEC, bool KSPLIT = false>
+template <int AK, bool SEC, bool KSPLIT = false, bool X3 = false>
 __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args A, const PwbSched sch, const int NB,
                                                         const int rows) {
     const trunet_wgrad_args& a = A.w;
@@ -386,6 +395,33 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
                 const int ra = my_rt * 32 + c;
                 // four frame groups of MFMAs; the prologue pass of tile t+1 runs in their shadow, a few row groups
                 // after each
+                if constexpr (X3) {
+#pragma unroll
+                    for (int qq = 0; qq < WFC / 16; ++qq) {
+                        // this lane's 8 frames of the K-step: 16 qq + 8 h .. + 7 = pieces 4 qq + 2 h, 4 qq + 2 h + 1 of its row
+                        u32x4 a0, a1, a2;
+                        ctx_split8(*(const f32x4*)(S + pwb_off(ra, 4 * qq + 2 * h)),
+                                   *(const f32x4*)(S + pwb_off(ra, 4 * qq + 2 * h + 1)), a0, a1, a2);
+#pragma unroll
+                        for (int i = 0; i < PMAXT; ++i) {
+                            if (rb_run[i] >= 0 && !(PWB_ABL & 16)) {
+                                u32x4 b0, b1, b2;
+                                ctx_split8(*(const f32x4*)(S + pwb_off(rb_run[i] + c, 4 * qq + 2 * h)),
+                                           *(const f32x4*)(S + pwb_off(rb_run[i] + c, 4 * qq + 2 * h + 1)), b0, b1, b2);
+                                CTX_MF6(acc[i], a0, a1, a2, b0, b1, b2);
+                            }
+                        }
+                        if (more && !(PWB_ABL & 4)) {
+                            if (qq == 0) pwb_wait_vmcnt((NB - 2) * LPW);      // tile t+1 has landed
+#pragma unroll
+                            for (int q = 2 * qq; q < 2 * qq + 2; ++q) {
+                                tpart(q, t + 1, nslot);
+                                tpart(q + 4, t + 1, nslot);
+                                if (PDW + PSW > 8) tpart(q + 8, t + 1, nslot);
+                            }
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int q = 0; q < WFC / 8; ++q) {
                     const f32x4 av = *(const f32x4*)(S + pwb_off(ra, 2 * q + h));
@@ -404,6 +440,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
                         tpart(q + 4, t + 1, nslot);
                         if (PDW + PSW > 8) tpart(q + 8, t + 1, nslot);
                     }
+                }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // tile t+1's prologue writes have landed
                 __builtin_amdgcn_s_barrier();                // every LDS read of tile t is done
@@ -470,16 +507,32 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
             const trunet_seg& usg = a.seg[useg];
             // some channel of this row tile has a BatchNorm weight of exactly zero (statistics: slow path below)
             const bool uzero = (uflags & TRUNET_DG_STATS) && __builtin_amdgcn_ballot_w64(CZ[ucb + 32 * uct + c][0] == 0.f) != 0;
-            float af[AH];
+            float af[X3 ? 1 : AH];
+            u32x4 ap[X3 ? AH / 8 : 1][3];      // X3: W^T fragment planes, lane (row ch, k = dz row 2 kh AH + 16 ks + 8 h + j)
             {
                 const int ch = 32 * uct + c;
                 const bool chok = ch < usg.nchan;
                 const float* wp = A.W + (size_t)a.w_m_off * a.ldw_m + (size_t)min(ch, usg.nchan - 1) * a.ldw_c + usg.woff;
+                if constexpr (X3) {
 #pragma unroll
-                for (int kk = 0; kk < AH; ++kk) {
-                    const int m = 2 * (kh * AH + kk) + h;
-                    const float v = wp[(size_t)min(m, a.M - 1) * a.ldw_m];
-                    af[kk] = (chok && m < a.M) ? v : 0.f;
+                    for (int ks = 0; ks < AH / 8; ++ks) {
+                        f32x4 w0, w1;
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj) {
+                            const int m = 2 * kh * AH + 16 * ks + 8 * h + jj;
+                            const float v = wp[(size_t)min(m, a.M - 1) * a.ldw_m];
+                            const float x = (chok && m < a.M) ? v : 0.f;
+                            if (jj < 4) w0[jj] = x; else w1[jj - 4] = x;
+                        }
+                        ctx_split8(w0, w1, ap[ks][0], ap[ks][1], ap[ks][2]);
+                    }
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < AH; ++kk) {
+                        const int m = 2 * (kh * AH + kk) + h;
+                        const float v = wp[(size_t)min(m, a.M - 1) * a.ldw_m];
+                        af[kk] = (chok && m < a.M) ? v : 0.f;
+                    }
                 }
             }
             float sa1[8], sa2[8];
@@ -528,12 +581,30 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
                         }
 #pragma unroll
                         for (int r = 0; r < 16; ++r) dacc[r] = 0.f;
-                        const float* Sb = S + (size_t)kh * AH * (2 * WFC) + h * WFC + (c & 3);
                         const int cpc = c >> 2;
+                        if constexpr (X3) {
+                            // B fragment of K-step ks: frame c, dz rows 2 kh AH + 16 ks + 8 h + j (j < 8); a row keeps its 16-byte
+                            // pieces XOR-swizzled by (row >> 1) & 7 = (4 h + (j >> 1)) & 7 (the K-step's first row is a multiple of 16)
+                            const float* Sb = S + (size_t)(2 * kh * AH + 8 * h) * WFC + (c & 3);
 #pragma unroll
-                        for (int kk = 0; kk < ((PWB_ABL & 32) ? 1 : AH); ++kk) {
-                            const float b = Sb[kk * (2 * WFC) + 4 * (cpc ^ (kk & 7))];
-                            dacc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], b, dacc, 0, 0, 0);
+                            for (int ks = 0; ks < ((PWB_ABL & 32) ? 1 : AH / 8); ++ks) {
+                                f32x4 x0, x1;
+#pragma unroll
+                                for (int jj = 0; jj < 4; ++jj) {
+                                    x0[jj] = Sb[(16 * ks + jj) * WFC + 4 * (cpc ^ ((4 * h + (jj >> 1)) & 7))];
+                                    x1[jj] = Sb[(16 * ks + 4 + jj) * WFC + 4 * (cpc ^ ((4 * h + 2 + (jj >> 1)) & 7))];
+                                }
+                                u32x4 b0, b1, b2;
+                                ctx_split8(x0, x1, b0, b1, b2);
+                                CTX_MF6(dacc, ap[ks][0], ap[ks][1], ap[ks][2], b0, b1, b2);
+                            }
+                        } else {
+                            const float* Sb = S + (size_t)kh * AH * (2 * WFC) + h * WFC + (c & 3);
+#pragma unroll
+                            for (int kk = 0; kk < ((PWB_ABL & 32) ? 1 : AH); ++kk) {
+                                const float b = Sb[kk * (2 * WFC) + 4 * (cpc ^ (kk & 7))];
+                                dacc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], b, dacc, 0, 0, 0);
+                            }
                         }
                         // hand over the 8 registers of the rows the partner wave finishes
 #pragma unroll
@@ -610,16 +681,34 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
             u.zero = (u.flags & TRUNET_DG_STATS) && __builtin_amdgcn_ballot_w64(CZ[u.cb + 32 * u.ct + c][0] == 0.f) != 0;
             return u;
         };
-        auto load_af = [&](const DUnit& u, float (&af)[AK]) __attribute__((always_inline)) {
+        // W^T fragments of a row tile: fp32 k-pairs, or (X3) three bf16 planes per K-step of 16 dz rows:
+        // lane (row ch = 32 ct + c, k = dz row 16 ks + 8 h + j, j < 8)
+        struct Frag { float af[X3 ? 1 : AK]; u32x4 ap[X3 ? AK / 8 : 1][3]; };
+        auto load_af = [&](const DUnit& u, Frag& fr) __attribute__((always_inline)) {
             const trunet_seg& sg = a.seg[max(u.seg, 0)];
             const int ch = 32 * u.ct + c;
             const bool chok = u.seg >= 0 && ch < sg.nchan;
             const float* wp = A.W + (size_t)a.w_m_off * a.ldw_m + (size_t)min(ch, sg.nchan - 1) * a.ldw_c + sg.woff;
+            if constexpr (X3) {
 #pragma unroll
-            for (int kk = 0; kk < AK; ++kk) {
-                const int m = 2 * kk + h;
-                const float v = wp[(size_t)min(m, a.M - 1) * a.ldw_m];     // all loads first, then the selects
-                af[kk] = (chok && m < a.M) ? v : 0.f;
+                for (int ks = 0; ks < AK / 8; ++ks) {
+                    f32x4 w0, w1;
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const int m = 16 * ks + 8 * h + jj;
+                        const float v = wp[(size_t)min(m, a.M - 1) * a.ldw_m];
+                        const float x = (chok && m < a.M) ? v : 0.f;
+                        if (jj < 4) w0[jj] = x; else w1[jj - 4] = x;
+                    }
+                    ctx_split8(w0, w1, fr.ap[ks][0], fr.ap[ks][1], fr.ap[ks][2]);
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < AK; ++kk) {
+                    const int m = 2 * kk + h;
+                    const float v = wp[(size_t)min(m, a.M - 1) * a.ldw_m];     // all loads first, then the selects
+                    fr.af[kk] = (chok && m < a.M) ? v : 0.f;
+                }
             }
         };
         auto begin_unit = [&](const DUnit& u, int p) __attribute__((always_inline)) {
@@ -647,7 +736,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
         float zv[16], ov[16];
         // head: epilogue operand loads (buffer resource + uniform row offset + per-lane offset), then the MFMAs over the
         // dz rows
-        auto dgrad_head = [&](const DUnit& u, const DRun& dr, const float (&af)[AK], const float* S, int n0)
+        auto dgrad_head = [&](const DUnit& u, const DRun& dr, const Frag& fr, const float* S, int n0)
                               __attribute__((always_inline)) {
             const __amdgpu_buffer_rsrc_t ro = pwb_rsrc(pwb_uniform(dr.ob));
             const int rowb = (int)(pwb_uniform(dr.dstride) * sizeof(float));      // bytes between channels
@@ -664,12 +753,29 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) dacc[r] = 0.f;
-            const float* Sb = S + h * WFC + (c & 3);
             const int cpc = c >> 2;
+            if constexpr (X3) {
+                // B fragment of K-step ks: frame c, dz rows 16 ks + 8 h + j (j < 8); swizzle term of a row: (4 h + (j >> 1)) & 7
+                const float* Sb = S + 8 * h * WFC + (c & 3);
 #pragma unroll
-            for (int kk = 0; kk < ((PWB_ABL & 32) ? 1 : AK); ++kk) {
-                const float b = Sb[kk * (2 * WFC) + 4 * (cpc ^ (kk & 7))];
-                dacc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], b, dacc, 0, 0, 0);
+                for (int ks = 0; ks < ((PWB_ABL & 32) ? 1 : AK / 8); ++ks) {
+                    f32x4 x0, x1;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        x0[jj] = Sb[(16 * ks + jj) * WFC + 4 * (cpc ^ ((4 * h + (jj >> 1)) & 7))];
+                        x1[jj] = Sb[(16 * ks + 4 + jj) * WFC + 4 * (cpc ^ ((4 * h + 2 + (jj >> 1)) & 7))];
+                    }
+                    u32x4 b0, b1, b2;
+                    ctx_split8(x0, x1, b0, b1, b2);
+                    CTX_MF6(dacc, fr.ap[ks][0], fr.ap[ks][1], fr.ap[ks][2], b0, b1, b2);
+                }
+            } else {
+                const float* Sb = S + h * WFC + (c & 3);
+#pragma unroll
+                for (int kk = 0; kk < ((PWB_ABL & 32) ? 1 : AK); ++kk) {
+                    const float b = Sb[kk * (2 * WFC) + 4 * (cpc ^ (kk & 7))];
+                    dacc = __builtin_amdgcn_mfma_f32_32x32x2f32(fr.af[kk], b, dacc, 0, 0, 0);
+                }
             }
         };
         // tail: accumulate / ReLU mask / statistics / store; FL = the segment's TRUNET_DG_* flags
@@ -730,7 +836,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
 
         const DUnit u1 = make_unit(sch.rt[j], sch.period[j], sch.phase[j], sch.share[j]);
         const DUnit u2 = make_unit(SEC ? sch.rt2[j] : -1, sch.period2[j], sch.phase2[j], sch.share2[j]);
-        float af1[AK], af2[SEC ? AK : 1];
+        Frag af1, af2;                                    // (af2 is dead code without SEC)
         load_af(u1, af1);
         if constexpr (SEC) load_af(u2, af2);
 
@@ -894,19 +1000,23 @@ extern "C" int trunet_pw_bwd(const trunet_pwbwd_args* H, void* stream) {
     }
     trunet_pwbwd_args HK = *H;          // the kernel compares the per-segment flags exactly: host-only bits stay on the host
     for (int s = 0; s < TRUNET_MAX_SEG; ++s) HK.dg[s].flags &= ~TRUNET_DG_PREZERO;
-#define PWB_LAUNCH(AK_, SEC_, KS_)                                                                                     \
+#define PWB_LAUNCH_(AK_, SEC_, KS_, X3_)                                                                                \
     do {                                                                                                               \
-        auto kern = pw_bwd_kernel<AK_, SEC_, KS_>;                                                                        \
+        auto kern = pw_bwd_kernel<AK_, SEC_, KS_, X3_>;                                                                   \
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
             return TRUNET_ELAUNCH;                                                                                     \
         hipLaunchKernelGGL(kern, dim3(PWB_GRID), dim3(512), lds, st, HK, sch, NB, rows);                               \
     } while (0)
+#define PWB_LAUNCH(AK_, SEC_, KS_) do { if (x3) PWB_LAUNCH_(AK_, SEC_, KS_, true); else PWB_LAUNCH_(AK_, SEC_, KS_, false); } while (0)
+    // both GEMMs on the bf16 MFMA through the three-term operand split (fp32-grade; the default: trunet_hip.h)
+    const bool x3 = (trunet_gemm_x3_enable(-1) & TRUNET_X3_BWD) != 0;
     if (MA == 32) PWB_LAUNCH(16, false, false);
     else if (MA == 64 && sec) PWB_LAUNCH(32, true, false);
     else if (MA == 64 && ksplit) PWB_LAUNCH(32, false, true);
     else if (MA == 64) PWB_LAUNCH(32, false, false);
     else if (ksplit) PWB_LAUNCH(64, false, true);
     else PWB_LAUNCH(64, false, false);
+#undef PWB_LAUNCH_
 #undef PWB_LAUNCH
     return trunet_launch_status();
 }

@@ -46,11 +46,12 @@ TGRU_LOOP = os.environ.get("TRUNET_TGRU_LOOP", "0") == "1"
 # PROFILE[kernel] = [(start_event, end_event, algorithmic_flops), ...]
 PROFILE = None
 PROFILE_LOG = None
+PROFILE_BYTES = {}           # kernel name -> algorithmic HBM bytes of the profiled launches (set next to PROFILE)
 
 
 class _Timed:
-    def __init__(self, name, flops=0.0, tag=""):
-        self.name, self.flops, self.tag = name, flops, tag
+    def __init__(self, name, flops=0.0, tag="", nbytes=0.0):
+        self.name, self.flops, self.tag, self.nbytes = name, flops, tag, nbytes
 
     def __enter__(self):
         if PROFILE is not None:
@@ -63,6 +64,8 @@ class _Timed:
         if PROFILE is not None:
             self.b.record()
             PROFILE.setdefault(self.name, []).append((self.a, self.b, self.flops))
+            if self.nbytes:          # algorithmic HBM bytes of the launch (kernels that are priced against the HBM roof)
+                PROFILE_BYTES[self.name] = PROFILE_BYTES.get(self.name, 0.0) + self.nbytes
             if PROFILE_LOG is not None:
                 PROFILE_LOG.append((self.name, self.tag, self.a, self.b, self.flops))
         return False
@@ -877,9 +880,14 @@ class TRUNetEngine:
                 fl_ = 4.0 * N * M * sum(s.nchan * _seg_positions(s, 0, P) for s in segs)
                 # the instance trunet_pw_bwd launches, as rocprofv3 prints it: <AK, SEC, KSPLIT> (KSPLIT: two source row tiles)
                 ksplit = K == 64 and os.environ.get("TRUNET_PWB_KSPLIT", "1") != "0"
-                name = "pw_bwd_kernel<%d, %s, %s>" % (16 if M <= 32 else (32 if M <= 64 else 64), "true" if K == 192 else "false",
-                                                      "true" if ksplit else "false")
-                with _Timed(name, fl_, "M%d K%s P%d" % (M, "+".join(str(s.nchan) for s in segs), P)):
+                name = "pw_bwd_kernel<%d, %s, %s, %s>" % (16 if M <= 32 else (32 if M <= 64 else 64), "true" if K == 192 else "false",
+                                                          "true" if ksplit else "false",
+                                                          "true" if lib.trunet_gemm_x3_enable(-1) & L.X3_BWD else "false")
+                # algorithmic bytes: dy and z_y once, every source row once, every gradient row written once (read as well
+                # where it accumulates), fp32, valid frames only
+                by_ = 4.0 * N * (2 * M * P + sum((3 if o.get("accum") else 2) * s.nchan * _seg_positions(s, 0, P)
+                                                 for s, o in zip(segs, outs)))
+                with _Timed(name, fl_, "M%d K%s P%d" % (M, "+".join(str(s.nchan) for s in segs), P), nbytes=by_):
                     rc = lib.trunet_pw_bwd(a, L.stream())
             else:
                 rc = lib.trunet_pw_bwd(a, L.stream())
@@ -973,7 +981,7 @@ class TRUNetEngine:
         a.b_stride, a.b_off = self._wg_total, 0
         if PROFILE is not None:
             fl = 4.0 * N * a.Ci * a.Co * sum(1 for q in range(a_pw.L) for kk in range(k) if 0 <= q * s_ - pad + kk < Lo)
-            x3 = lib.trunet_gemm_x3_enable(-1)
+            x3 = lib.trunet_gemm_x3_enable(-1) & L.X3_BWD
             with _Timed("convt_bwd%s_kernel<%d, %d>" % ("_x3" if x3 else "", k, s_), fl, "L%d" % a_pw.L):
                 rc = lib.trunet_convt_bwd(a, L.stream())
         else:
