@@ -352,7 +352,7 @@ extern "C" int trunet_convt_bwd(const trunet_convt_bwd_args* h, void* stream) {
     // 32-bit byte offsets of the buffer stores: 36 channel rows of the gradient tensor below 2 GiB
     if ((size_t)h->Lin * h->NP * sizeof(float) * 36 >= ((size_t)1 << 31)) return TRUNET_ENOTSUP;
     hipStream_t st = (hipStream_t)stream;
-    if (trunet_gemm_x3_enable(-1) & TRUNET_X3_BWD) return trunet_launch_convt_bwd_x3(h, st);
+    if (trunet_gemm_x3_enable(-1) & (TRUNET_X3_BWD | 8)) return trunet_launch_convt_bwd_x3(h, st);
     if (h->K == 3 && h->S == 1) return ct_launch<3, 1>(h, st);
     if (h->K == 3 && h->S == 2) return ct_launch<3, 2>(h, st);
     if (h->K == 5 && h->S == 2) return ct_launch<5, 2>(h, st);

@@ -234,14 +234,13 @@ __global__ __launch_bounds__(256) void pcen_scan_kernel(const float* __restrict_
     }
 }
 
-// (x / (M + eps)^alpha + delta)^r - delta^r  (dataset.py:70-75).  The two powers through the hardware's base-2 exponential and
-// logarithm (v_exp_f32 / v_log_f32, ~1 ulp each: the result within ~2e-6 relative of powf for the dynamic range of an STFT
-// magnitude), the outer one as a square root for the reference's r = 0.5: three powf calls per element (~300 instructions)
-// made pcen_pow_kernel compute-bound at 0.136 ms for 100 MB of traffic.
+// (x / (M + eps)^alpha + delta)^r - delta^r  (dataset.py:70-75), shared by the offline and the streaming front end.  libm's powf on
+// purpose: the two powers through v_exp_f32 / v_log_f32 (and a square root for r = 0.5) were built in round 4 -- 0.135 -> ~0.06 ms
+// per step, features within 2e-6 -- and taken out again: a 1e-6 change of the network INPUT moves the full-size gradients as far
+// as any other change of the forward rounding does (test_cfg2_full_size_train_step_vs_oracle: 8.6e-4 -> 2.1e-2 against the
+// oracle at the gated seed), and the features are pinned to the reference's torch.pow.
 __device__ __forceinline__ float pcen_value(float v, float M, float eps, float alpha, float delta, float r, float dr) {
-    const float t = v * __builtin_amdgcn_exp2f(-alpha * __builtin_amdgcn_logf(M + eps)) + delta;
-    const float o = (r == 0.5f) ? __builtin_amdgcn_sqrtf(t) : __builtin_amdgcn_exp2f(r * __builtin_amdgcn_logf(t));
-    return o - dr;
+    return powf(v / powf(M + eps, alpha) + delta, r) - dr;
 }
 
 __global__ __launch_bounds__(256) void pcen_pow_kernel(const float* __restrict__ mag, float* __restrict__ out, int rows,

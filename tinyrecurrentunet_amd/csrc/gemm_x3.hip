@@ -348,7 +348,7 @@ extern "C" int trunet_gemm_x3_enable(int on) {
         g_x3_on = (e && e[0] >= '0' && e[0] <= '3' && !e[1]) ? e[0] - '0' : TRUNET_X3_BWD;
     }
     const int prev = g_x3_on;
-    if (on >= 0) g_x3_on = on & (TRUNET_X3_GEMM | TRUNET_X3_BWD);
+    if (on >= 0) g_x3_on = on & (TRUNET_X3_GEMM | TRUNET_X3_BWD | 4 | 8);     // 4 / 8 (diagnostics): only pw_bwd / only convt_bwd
     return prev;
 }
 

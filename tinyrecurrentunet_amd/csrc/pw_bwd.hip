@@ -1017,7 +1017,7 @@ extern "C" int trunet_pw_bwd(const trunet_pwbwd_args* H, void* stream) {
     } while (0)
 #define PWB_LAUNCH(AK_, SEC_, KS_) do { if (x3) PWB_LAUNCH_(AK_, SEC_, KS_, true); else PWB_LAUNCH_(AK_, SEC_, KS_, false); } while (0)
     // both GEMMs on the bf16 MFMA through the three-term operand split (fp32-grade; the default: trunet_hip.h)
-    const bool x3 = (trunet_gemm_x3_enable(-1) & TRUNET_X3_BWD) != 0;
+    const bool x3 = (trunet_gemm_x3_enable(-1) & (TRUNET_X3_BWD | 4)) != 0;
     if (MA == 32) PWB_LAUNCH(16, false, false);
     else if (MA == 64 && sec) PWB_LAUNCH(32, true, false);
     else if (MA == 64 && ksplit) PWB_LAUNCH(32, false, true);
