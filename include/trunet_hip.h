@@ -432,6 +432,13 @@ size_t trunet_stream_fwd_scratch_floats(int grid);
 int trunet_stream_fwd_check(const int32_t* h_offsets, int n_offsets, int64_t blob_numel, int Cin);
 int trunet_stream_fwd(const float* x, float* y, const float* blob, const int32_t* h_offsets, int n_offsets,
                       int64_t blob_numel, float* scratch, const float* h_in, float* h_out, int N, int Cin, void* stream);
+/* The same forward with the matrix layers named in stream_fwd_x3.hip on the bf16 MFMA through the three-term split of the fp32
+ * operands (fp32-grade result: section 3b of DESIGN.md): identical contract, but `blob` is the image export.x3_image() derives
+ * from the folded one -- those layers' weights as three bf16 fragment planes (an exact split of the folded fp32 weights), every
+ * other section bit for bit -- passed as 32-bit words; trunet_stream_fwd_x3_check is its bounds check. */
+int trunet_stream_fwd_x3_check(const int32_t* h_offsets, int n_offsets, int64_t blob_numel, int Cin);
+int trunet_stream_fwd_x3(const float* x, float* y, const float* blob, const int32_t* h_offsets, int n_offsets,
+                         int64_t blob_numel, float* scratch, const float* h_in, float* h_out, int N, int Cin, void* stream);
 
 /* ---- input pipeline on the GPU ----
  * DataAugment.__call__ + the clean/noise mix (dataset.py:116-126, :380) for a whole batch resident in HBM:

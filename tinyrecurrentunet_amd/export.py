@@ -14,6 +14,7 @@ causal stream of rt.py:20-27 / stream.py:83-109: ``FoldedTRUNet.stream_step(x, h
 position) sequence by ONE GRU time step inside the same single launch (between FGRU.conv and decoder.0, as drawn in
 docs/net.jpg); the hidden state h (streams, 128, 16) lives in HBM, 8 KB per stream, read and written by the kernel."""
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -75,6 +76,99 @@ def _frag_tiles16(Wm, bias):
         out.append(np.concatenate([A.reshape(-1), Bq.reshape(-1)]))
     return np.concatenate(out)
 
+
+def _unfrag_tiles(sec, M, K):
+    """Inverse of _frag_tiles: the section of a folded image -> (W (M, K), bias (M,)) float32."""
+    nrt = (M + 31) // 32
+    KP = (K + 15) // 16 * 8
+    per = KP * 64 + 16 * 64
+    sec = np.asarray(sec, dtype=np.float32)[:nrt * per].reshape(nrt, per)
+    lane = np.arange(64)
+    W = np.zeros((nrt * 32, 2 * KP), dtype=np.float32)
+    b = np.zeros(nrt * 32, dtype=np.float32)
+    r = np.arange(16)
+    for rt in range(nrt):
+        A = sec[rt, :KP * 64].reshape(KP // 4, 64, 4).transpose(0, 2, 1).reshape(KP, 64)          # (kp, lane)
+        rows = rt * 32 + (lane & 31)
+        W[rows[None, :], 2 * np.arange(KP)[:, None] + (lane >> 5)[None, :]] = A
+        Bq = sec[rt, KP * 64:].reshape(4, 64, 4).transpose(0, 2, 1).reshape(16, 64)               # (r, lane)
+        brow = rt * 32 + (r & 3)[:, None] + 8 * (r >> 2)[:, None] + 4 * (lane >> 5)[None, :]
+        b[brow] = Bq
+    return W[:M, :K], b[:M]
+
+
+def _bf16_rne(x):
+    """float32 array -> the nearest bf16 values (ties to even) as float32 (finite inputs)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    u = (u + (((u >> 16) & 1) + np.uint32(0x7FFF))) & np.uint32(0xFFFF0000)
+    return u.view(np.float32)
+
+
+def _split3(x):
+    """x (float32) = hi + mid + lo, three bf16 terms rounded to nearest, the residues exact in fp32 (x3_common.hpp) -> three
+    uint16 arrays (the bf16 bit patterns)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    hi = _bf16_rne(x)
+    r1 = x - hi
+    mid = _bf16_rne(r1)
+    lo = _bf16_rne(r1 - mid)
+    return [(p.view(np.uint32) >> 16).astype(np.uint16) for p in (hi, mid, lo)]
+
+
+def _frag_tiles_x3(Wm, bias):
+    """Wm (M, K) float32, bias (M,): per 32-row tile [K/16 K-steps x 3 planes: one quad each][4 quads of bias (fp32 bits)], each
+    quad [64 lanes][4 words].  Lane l holds the 8 bf16 values A[row l & 31][k = 16 ks + 8 (l >> 5) + 0..7] of a plane
+    (v_mfma_f32_32x32x16_bf16 A operand; two values per word, the lower k in the lower half) -> uint32 array."""
+    M, K = Wm.shape
+    nrt = (M + 31) // 32
+    KS = (K + 15) // 16
+    Wp = np.zeros((nrt * 32, 16 * KS), dtype=np.float32)
+    Wp[:M, :K] = Wm
+    bp = np.zeros(nrt * 32, dtype=np.float32)
+    bp[:M] = bias
+    planes = _split3(Wp)
+    lane = np.arange(64)
+    r = np.arange(16)
+    out = []
+    for rt in range(nrt):
+        rows = rt * 32 + (lane & 31)
+        for ks in range(KS):
+            k0 = 16 * ks + 8 * (lane >> 5)
+            for pl in planes:
+                v = pl[rows[:, None], k0[:, None] + np.arange(8)[None, :]].astype(np.uint32)      # (lane, 8)
+                out.append((v[:, 0::2] | (v[:, 1::2] << 16)).reshape(-1))                         # (lane, 4 words)
+        brow = rt * 32 + (r & 3)[:, None] + 8 * (r >> 2)[:, None] + 4 * (lane >> 5)[None, :]
+        out.append(bp[brow].reshape(4, 4, 64).transpose(0, 2, 1).reshape(-1).view(np.uint32))
+    return np.concatenate(out)
+
+
+def x3_image(blob, offsets):
+    """The image `trunet_stream_fwd_x3` reads (round 4): the folded image with the pointwise weights of encoder.1 .. encoder.5 as
+    three bf16 fragment planes (exact three-term split of the folded fp32 weights; everything else bit for bit) -> (uint32 blob,
+    offsets)."""
+    blob = np.ascontiguousarray(np.asarray(blob, dtype=np.float32))
+    offsets = np.asarray(offsets, dtype=np.int64)
+    starts = sorted(set(int(offsets[i]) for i in range(N_OFFSETS) if i < 26 or offsets[i] > 0))
+    bounds = {a: b for a, b in zip(starts, starts[1:] + [len(blob)])}
+    sec, offs = [], []
+    for i in range(N_OFFSETS):
+        if i >= 26 and offsets[i] == 0:
+            offs.append(0)
+            continue
+        a = int(offsets[i])
+        raw = blob[a:bounds[a]]
+        if 1 <= i <= 5:                              # o_pw[5]: encoder.1 (K = 64), encoder.2..5 (K = 128), 128 rows each
+            W, b = _unfrag_tiles(raw, 128, 64 if i == 1 else 128)
+            raw = _frag_tiles_x3(W, b)
+        else:
+            raw = raw.view(np.uint32)
+        offs.append(sum(len(x) for x in sec))
+        sec.append(raw)
+    return np.concatenate(sec).astype(np.uint32), np.array(offs, dtype=np.int32)
+
+
+# which kernel a FoldedTRUNet launches by default (FoldedTRUNet.use_x3 switches an instance)
+STREAM_X3 = os.environ.get("TRUNET_STREAM_X3", "0") == "1"
 
 N_OFFSETS = 30          # 26 sections of the stateless forward + 4 of the time-recurrent block (0 when not exported)
 
@@ -189,6 +283,29 @@ class FoldedTRUNet:
         self.cin = int(cin)
         self.has_tgru = bool(offsets[26] > 0)
         self._scratch = None
+        # the same image with the encoder's pointwise weights as three bf16 fragment planes, for trunet_stream_fwd_x3
+        # (STREAM_X3: which kernel forward() launches)
+        self.x3 = STREAM_X3
+        self.blob_x3 = self._offs_x3 = None
+        if self.x3:
+            self._make_x3()
+
+    def _make_x3(self):
+        b3, o3 = x3_image(self.blob.cpu().numpy(), self.offsets)
+        rc = L.lib().trunet_stream_fwd_x3_check(o3.ctypes.data_as(C.POINTER(C.c_int32)), len(o3), len(b3), self.cin)
+        if rc != L.TRUNET_OK:
+            raise L.TrunetHipError("internal: the bf16-plane image fails its own bounds check")
+        self.blob_x3 = torch.from_numpy(b3.view(np.int32).copy()).to(self.blob.device)
+        self.offsets_x3 = o3
+        self._offs_x3 = (C.c_int32 * len(o3))(*[int(v) for v in o3])
+
+    def use_x3(self, on=True):
+        """Select the kernel of forward() / stream_step(): trunet_stream_fwd_x3 (encoder pointwise layers on the bf16 MFMA through
+        the three-term split) or trunet_stream_fwd (fp32 MFMA everywhere)."""
+        self.x3 = bool(on)
+        if self.x3 and self.blob_x3 is None:
+            self._make_x3()
+        return self
 
     @classmethod
     def from_module(cls, net, device=None, tgru=False):
@@ -231,8 +348,13 @@ class FoldedTRUNet:
         if self._scratch is None or self._scratch.numel() < need or self._scratch.device != x.device:
             self._scratch = torch.empty(need, device=x.device, dtype=torch.float32)
         y = torch.empty((N, 8, 257), device=x.device, dtype=torch.float32)
-        check(lib.trunet_stream_fwd(ptr(x), ptr(y), ptr(self.blob), self._offs, len(self.offsets), self.blob.numel(),
-                                    ptr(self._scratch), ptr(h_in), ptr(h_out), N, self.cin, L.stream()), "stream_fwd")
+        if self.x3:
+            check(lib.trunet_stream_fwd_x3(ptr(x), ptr(y), self.blob_x3.data_ptr(), self._offs_x3, len(self.offsets_x3),
+                                           self.blob_x3.numel(), ptr(self._scratch), ptr(h_in), ptr(h_out), N, self.cin,
+                                           L.stream()), "stream_fwd_x3")
+        else:
+            check(lib.trunet_stream_fwd(ptr(x), ptr(y), ptr(self.blob), self._offs, len(self.offsets), self.blob.numel(),
+                                        ptr(self._scratch), ptr(h_in), ptr(h_out), N, self.cin, L.stream()), "stream_fwd")
         return y
 
     def forward(self, x):
