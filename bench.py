@@ -262,8 +262,13 @@ def streaming(args, dev, emit=True):
         flops += streams * 2.0 * (384 * 64 + 384 * 128 + 64 * 128) * 16
     ach = flops / (kms * 1e-3) / 1e12
     folded = bool(net.__dict__.get("_folded_cache")) and (state is None or state.layout == "folded")
-    roof = {"bound": "mfma", "kernel": ("stream_fwd_kernel<%s>" % ("true" if args.tgru else "false")) if folded
+    from tinyrecurrentunet_amd import export as texport
+    x3 = texport.STREAM_X3
+    roof = {"bound": "mfma", "kernel": ("stream_fwd%s_kernel<%s>" % ("_x3" if x3 else "", "true" if args.tgru else "false")) if folded
             else "layer-by-layer launches",
+            # priced against the fp32 MFMA peak in fp32-equivalent flops; with the split kernel (the default) the encoder's
+            # pointwise layers -- 42 % of the flops -- run on the bf16 MFMA (six bf16 multiply-adds per fp32 one)
+            "mfma": "fp32, encoder pointwise layers bf16x3" if x3 else "fp32",
             "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4),
             "traffic": None, "avg_launch_ms": round(kms, 4),
             # features in + output out per frame (+ the hidden state read and written: 2 x 8 KB)

@@ -436,6 +436,7 @@ int trunet_stream_fwd(const float* x, float* y, const float* blob, const int32_t
  * operands (fp32-grade result: section 3b of DESIGN.md): identical contract, but `blob` is the image export.x3_image() derives
  * from the folded one -- those layers' weights as three bf16 fragment planes (an exact split of the folded fp32 weights), every
  * other section bit for bit -- passed as 32-bit words; trunet_stream_fwd_x3_check is its bounds check. */
+int trunet_stream_fwd_x3_mask(void);     /* layer groups on the split path in this build (export._X3_SECTIONS) */
 int trunet_stream_fwd_x3_check(const int32_t* h_offsets, int n_offsets, int64_t blob_numel, int Cin);
 int trunet_stream_fwd_x3(const float* x, float* y, const float* blob, const int32_t* h_offsets, int n_offsets,
                          int64_t blob_numel, float* scratch, const float* h_in, float* h_out, int N, int Cin, void* stream);

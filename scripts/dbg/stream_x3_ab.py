@@ -4,7 +4,11 @@ import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import network_ref as nr, weights as W
+from tinyrecurrentunet_amd import _lib as L
+if os.environ.get("TRUNET_HIP_LIB"):      # A/B builds of the library (other SFX_MASK values)
+    L.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), os.environ["TRUNET_HIP_LIB"])
 from tinyrecurrentunet_amd import export, network as hn
+print("SFX_MASK", L.lib().trunet_stream_fwd_x3_mask())
 
 torch.manual_seed(0)
 ref = W.fill_state_dict(nr.TRUNet(input_size=4), seed=2)

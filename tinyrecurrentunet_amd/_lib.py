@@ -206,6 +206,7 @@ def _declare(L):
         "trunet_stream_fwd_scratch_floats": [i],
         "trunet_stream_fwd_check": [C.POINTER(C.c_int32), i, i64, i],
         "trunet_stream_fwd": [p, p, p, C.POINTER(C.c_int32), i, i64, p, p, p, i, i, p],
+        "trunet_stream_fwd_x3_mask": [],
         "trunet_stream_fwd_x3_check": [C.POINTER(C.c_int32), i, i64, i],
         "trunet_stream_fwd_x3": [p, p, p, C.POINTER(C.c_int32), i, i64, p, p, p, i, i, p],
         "trunet_bf16_gemm_nparts": [],

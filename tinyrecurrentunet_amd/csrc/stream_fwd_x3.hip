@@ -365,6 +365,126 @@ __device__ __forceinline__ void sf_convT16(const float* af, float* lds, int src,
     }
 }
 
+// ---- 16-row tiles on the bf16 MFMA (v_mfma_f32_16x16x32_bf16): acc[ct] += A * B over KS K-steps of 32 and NCT column tiles of
+// 16.  A: three bf16 planes per K-step in af (12 words per K-step); lane l holds A[row l & 15][k = 32 ks + 8 (l >> 4) + j] and
+// B[k = 32 ks + 8 (l >> 4) + j][column l & 15] (j < 8); S is the lane's base (row 8 (l >> 4), column l & 15), element (ks, j,
+// ct) at S[(32 ks + j) * ls + 16 ct].  A unit = (K-step, column tile): 8 ds_read_b32 issued one unit ahead, the split of the
+// NEXT unit's values between the six MFMAs of this one (the unit is vector-bound: 36 split instructions for 6 x 16 cycles).
+template <int KS, int NCT>
+__device__ __forceinline__ void sf_mm16_x3(f32x4 (&acc)[NCT], const float* af, const float* S, int ls) {
+    constexpr int NU = KS * NCT;
+    const sf_lptr S0 = sf_lds_base(S), S1 = sf_lds_base(S + (KS > 2 ? 64 : 0) * ls);      // 64 rows x 576 B per base
+#define SF_B(u, j) ((32 * ((u) / NCT) + (j)) < 64 ? S0[(32 * ((u) / NCT) + (j)) * ls + 16 * ((u) % NCT)] \
+                                                   : S1[(32 * ((u) / NCT) + (j) - 64) * ls + 16 * ((u) % NCT)])
+#define SF_MF16(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), acc_, 0, 0, 0)
+    auto plane = [&](int ks, int pl) __attribute__((always_inline)) {
+        const float* p = af + (ks * 3 + pl) * 4;
+        return u32x4{__builtin_bit_cast(unsigned, p[0]), __builtin_bit_cast(unsigned, p[1]), __builtin_bit_cast(unsigned, p[2]),
+                     __builtin_bit_cast(unsigned, p[3])};
+    };
+    float x[8];
+    u32x4 b0, b1, b2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = SF_B(0, j);
+    {
+        unsigned u0, u1, u2;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { ctx_split2(x[2 * w], x[2 * w + 1], u0, u1, u2); b0[w] = u0; b1[w] = u1; b2[w] = u2; }
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int ks = u / NCT, ct = u % NCT;
+        const u32x4 a0 = plane(ks, 0), a1 = plane(ks, 1), a2 = plane(ks, 2);
+        const bool nx = u + 1 < NU;
+        u32x4 n0 = b0, n1 = b1, n2 = b2;
+        unsigned u0, u1, u2;
+        if (nx) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = SF_B(u + 1, j);
+        }
+        SF_SB(); SF_MF16(acc[ct], a2, b0); SF_SB();
+        SF_SB(); SF_MF16(acc[ct], a0, b2); SF_SB();
+        if (nx) { ctx_split2(x[0], x[1], u0, u1, u2); n0[0] = u0; n1[0] = u1; n2[0] = u2; }
+        SF_SB(); SF_MF16(acc[ct], a1, b1); SF_SB();
+        if (nx) { ctx_split2(x[2], x[3], u0, u1, u2); n0[1] = u0; n1[1] = u1; n2[1] = u2; }
+        SF_SB(); SF_MF16(acc[ct], a1, b0); SF_SB();
+        if (nx) { ctx_split2(x[4], x[5], u0, u1, u2); n0[2] = u0; n1[2] = u1; n2[2] = u2; }
+        SF_SB(); SF_MF16(acc[ct], a0, b1); SF_SB();
+        if (nx) { ctx_split2(x[6], x[7], u0, u1, u2); n0[3] = u0; n1[3] = u1; n2[3] = u2; }
+        SF_SB(); SF_MF16(acc[ct], a0, b0); SF_SB();
+        b0 = n0; b1 = n1; b2 = n2;
+    }
+#undef SF_B
+}
+
+// sf_pw16 on the split path: KS1 / KS2 K-steps of 32 over the two sources (af: 12 (KS1 + KS2) words of planes, then 4 bias values)
+template <int KS1, int KS2, int NCT, bool SPLIT, bool FULL, bool RELU = true>
+__device__ __forceinline__ void sf_pw16_x3(const float* af, float* lds, int src1, int ls1, int coff1, int src2, int ls2, int dst,
+                                           int lsd, int P, int M, int rowbase = -1) {
+    const int tid_ = sf_tid();
+    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), q = lane >> 4, j = lane & 15;
+    const int row = (rowbase >= 0 ? rowbase : (SPLIT ? 0 : 16 * wave)) + 4 * q;
+    const int ng = (P + 16 * NCT - 1) / (16 * NCT);
+    for (int g = SPLIT ? wave : 0; g < ng; g += SPLIT ? 4 : 1) {
+        f32x4 acc[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int c0 = g * 16 * NCT + j;
+        sf_mm16_x3<KS1, NCT>(acc, af, lds + src1 + 8 * q * ls1 + 4 + c0 + coff1, ls1);
+        if constexpr (KS2 > 0) sf_mm16_x3<KS2, NCT>(acc, af + 12 * KS1, lds + src2 + 8 * q * ls2 + 4 + c0, ls2);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const int col = c0 + 16 * ct;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[ct][r] + af[12 * (KS1 + KS2) + r];
+                if (RELU) v = fmaxf(v, 0.f);
+                if (FULL || (col < P && row + r < M)) lds[dst + (row + r) * lsd + 4 + col] = v;
+            }
+        }
+    }
+}
+
+// sf_convT16 on the split path: per tap K = 64 = two K-steps (af: 24 words per tap, then 4 bias values)
+template <int TAPS, int S_, int NCT, bool FULL>
+__device__ __forceinline__ void sf_convT16_x3(const float* af, float* lds, int src, int lsi, int dst, int lsd, int Lout,
+                                              int p0, int Ln) {
+    const int tid_ = sf_tid();
+    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), q = lane >> 4, j = lane & 15;
+    constexpr int PAD = S_ / 2;
+    const int pend = min(Lout, p0 + Ln);
+    const int row = 16 * wave + 4 * q;
+#pragma unroll
+    for (int e = 0; e < S_; ++e) {
+        const int j0 = p0 > e ? (p0 - e + S_ - 1) / S_ : 0;
+        const int nj = (pend - e + S_ - 1) / S_ - j0;
+        const int ng = (nj + 16 * NCT - 1) / (16 * NCT);
+        for (int g = 0; g < ng; ++g) {
+            f32x4 acc[NCT];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int c0 = j0 + g * 16 * NCT + j;
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                constexpr int BIG = 8 * S_;
+                if ((e + PAD - tap + BIG) % S_ == 0) {
+                    const int d = (e + PAD - tap + BIG) / S_ - 8;
+                    sf_mm16_x3<2, NCT>(acc, af + tap * 24, lds + src + 8 * q * lsi + 4 + c0 + d, lsi);
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const int p = S_ * (c0 + 16 * ct) + e;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = fmaxf(acc[ct][r] + af[TAPS * 24 + r], 0.f);
+                    if (FULL || p < pend) lds[dst + (row + r) * lsd + 4 + p] = v;
+                }
+            }
+        }
+    }
+}
+
 // depthwise conv (k = K, stride S, padding K/2) + folded BatchNorm + ReLU; weights staged in LDS at `wl` ([C][K] then [C]).
 // A lane produces 4 consecutive outputs of one channel row from the 16-byte quads that cover its input window
 // (conflict-free: consecutive lanes read consecutive quads of a row).  Lout is a multiple of 4.
@@ -468,16 +588,41 @@ struct SfArgs {
 constexpr int LSA = sf_ls(128);          // one row stride (144 floats) for every activation buffer: immediate LDS offsets
 constexpr int LSG = sf_ls(16);           // ... except the GRU projection [384][32]
 
+// Which matrix layers multiply on the bf16 MFMA (the others run the fp32-MFMA code of stream_fwd.hip); export.x3_image builds the
+// image for the mask the library reports.  Measured per mask (1x MI355X, 1024 frames per launch, scripts/dbg/stream_x3_ab.py;
+// all-fp32-MFMA kernel 0.4397 ms): 1 -> 0.4086, 3 -> 0.4214, 7 -> 0.4273, 15 -> 0.4384, 19 -> 0.4305, 31 -> 0.4493 ms.  With one
+// wave per SIMD the unit (6 MFMAs + the split of the next fragment: ~46 vector / LDS instructions) is bound by instruction issue
+// at ~310 cycles: 1.7x over eight 66-cycle v_mfma_f32_32x32x2_f32, but slower than eight 35-cycle v_mfma_f32_16x16x4_f32 on the
+// 16-row layers -- so only the 32-row encoder layers take the split path (and the kernel stays inside the 64 KB instruction
+// cache: 55.5 KB; mask 31 is 71.5 KB).
+#ifndef SFX_MASK
+#define SFX_MASK 1
+#endif
+constexpr bool XE = (SFX_MASK & 1) != 0;     // encoder.1 .. encoder.5 pointwise (32-row tiles)
+constexpr bool XD = (SFX_MASK & 2) != 0;     // decoder.1 .. decoder.4 pointwise (192 -> 64)
+constexpr bool XC3 = (SFX_MASK & 4) != 0;    // decoder.2 / decoder.4 transposed conv (k3 s1)
+constexpr bool XC5 = (SFX_MASK & 8) != 0;    // decoder.1 / decoder.3 transposed conv (k5 s2)
+constexpr bool XO = (SFX_MASK & 16) != 0;    // GRU projection, FGRU.conv, decoder.0, decoder.5 pointwise, the TGRU block
+constexpr int NQ_E1 = XE ? 16 : 12, NQ_E = XE ? 28 : 20;             // quads per 32-row tile: encoder.1, encoder.2..5
+constexpr int NQ_T16 = XO ? 13 : 9;                                   // 16-row tile, K = 128
+constexpr int NQ_D0 = XO ? 7 : 5, NQ_C0 = XO ? 19 : 13;               // decoder.0 pointwise, transposed conv (k3 s2)
+constexpr int NQ_D = XD ? 19 : 13;                                    // decoder.1..4 pointwise (K = 192)
+constexpr int NQ_C3 = XC3 ? 19 : 13, NQ_C5 = XC5 ? 31 : 21;           // transposed convs k3 s1 / k5 s2
+constexpr int NQ_CMAX = NQ_C5 > NQ_C3 ? NQ_C5 : NQ_C3;
+constexpr int NQ_RZ = XO ? 19 : 13, NQ_IN = XO ? 7 : 5;               // TGRU: r/z tile (K = 64 + 128), n rows of W_ih (K = 64)
+constexpr int RQ_E = NQ_E > 2 * NQ_T16 ? NQ_E : 2 * NQ_T16;           // encoder loop request (the last one fetches a projection pass)
+constexpr int NQ_MAX = RQ_E > NQ_CMAX ? RQ_E : NQ_CMAX;
+
 // TG: with the time-recurrent block (network.py:150; GRUBlock :45-58) between FGRU.conv and decoder.0: one GRU time step per
 // (stream, frequency position), hidden state (128 x 16 per stream) read from / written to HBM.  Its own instance, so that
 // the stateless kernel's code footprint (instruction cache) stays what it was.
 template <bool TG>
-__global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
+__global__ __launch_bounds__(SF_T, 1) void stream_fwd_x3_kernel(const SfArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* skip = A.scratch + (size_t)blockIdx.x * SF_SKIP;
     float* sk0 = skip, *sk1 = sk0 + 8192, *sk2 = sk1 + 16384, *sk3 = sk2 + 8192, *sk4 = sk3 + 8192;
-    float fs[112], fp[112];                      // compute set / staging set (A fragments + bias values of a wave's row tile(s))
+    float fs[4 * NQ_MAX], fp[4 * NQ_MAX];                      // compute set / staging set (A fragments + bias values of a wave's row tile(s))
     const int Cin = A.Cin;
 
     // first-conv weights: resident for the whole kernel
@@ -505,7 +650,7 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
         const float* blob = A.blob + opaque0;
         // ---------------- features -> LDS, first conv (C_in -> 64, k5 s2 p1) + ReLU            network.py:9-21
         SF_STAMP(0);
-        SF_REQUEST(16, A.o_pw[0], wave);                                    // encoder.1 pw: K = 64 -> 4 K-steps x 3 planes + bias
+        SF_REQUEST(NQ_E1, A.o_pw[0], wave);                                 // encoder.1 pw (K = 64)
         {
             constexpr int LSX = sf_ls(257);
             // the frame's features were requested at the end of the previous frame (xr): zero-padded rows into LDS
@@ -573,9 +718,10 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
             float dwr[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) dwr[j] = blob[A.o_dw[0] + tid + SF_T * j];
-            SF_TAKE(16);
-            SF_REQUEST(28, A.o_pw[1], wave);
-            sf_pw_x3<4>(fs, lds, SF_R0, LSA, SF_R1A, LSA, 128);
+            SF_TAKE(NQ_E1);
+            SF_REQUEST(NQ_E, A.o_pw[1], wave);
+            if constexpr (XE) sf_pw_x3<4>(fs, lds, SF_R0, LSA, SF_R1A, LSA, 128);
+            else sf_pw<32, 0, 4>(fs, lds, SF_R0, LSA, 0, 0, 0, SF_R1A, LSA, 128, 128, 0, true);
             sf_guards(lds, SF_R1A, 128, LSA, 128);
 #pragma unroll
             for (int j = 0; j < 2; ++j) lds[SF_DWB + tid + SF_T * j] = dwr[j];
@@ -597,18 +743,19 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) dwr[j] = blob[A.o_dw[1 + it] + tid + SF_T * j];
             if (it == 1) SF_STAMP(27);
-            SF_TAKE(28);
+            SF_TAKE(RQ_E);
 #ifdef SF_STAMPS
             if (it == 1) { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); SF_STAMP(28); }
 #endif
             {
                 // next: encoder.(3 + it) (20 quads per 32-row tile), or the first projection pass (two 16-row tiles = 18
                 // quads; the request reads 20: inside the blob)
-                const int off_ = it < 3 ? A.o_pw[2 + it] + wave * 7168 : A.o_gi + 2 * wave * 2304;
-                SF_REQUEST(28, off_, 0);
+                const int off_ = it < 3 ? A.o_pw[2 + it] + wave * (NQ_E * 256) : A.o_gi + 2 * wave * (NQ_T16 * 256);
+                SF_REQUEST(RQ_E, off_, 0);
             }
             if (it == 1) SF_STAMP(29);
-            sf_pw_x3<8>(fs, lds, SF_R0, LSA, SF_R1A, LSA, L);
+            if constexpr (XE) sf_pw_x3<8>(fs, lds, SF_R0, LSA, SF_R1A, LSA, L);
+            else sf_pw<64, 0, 4>(fs, lds, SF_R0, LSA, 0, 0, 0, SF_R1A, LSA, L, 128, 0, true);
             if (it == 1) SF_STAMP(30);
             sf_guards(lds, SF_R1A, 128, LSA, L);
 #pragma unroll
@@ -627,16 +774,21 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
         // GRU input projection (384 x 128, both directions; network.py:45-58,149) over the 16 positions: 24 row tiles of
         // 16 (one exact 16 x 16 tile each; 32-row tiles were half empty), three passes of two tiles per wave
         for (int ps = 0; ps < 3; ++ps) {
-            SF_TAKE(18);
+            SF_TAKE(2 * NQ_T16);
             {
-                // next pass, or FGRU.conv (128 -> 64: four 16-row tiles of 9 quads; the request reads 18)
-                const int off_ = ps < 2 ? A.o_gi + (8 * (ps + 1) + 2 * wave) * 2304 : A.o_fg + wave * 2304;
-                SF_REQUEST(18, off_, 0);
+                // next pass, or FGRU.conv (128 -> 64: four 16-row tiles; the request reads two)
+                const int off_ = ps < 2 ? A.o_gi + (8 * (ps + 1) + 2 * wave) * (NQ_T16 * 256) : A.o_fg + wave * (NQ_T16 * 256);
+                SF_REQUEST(2 * NQ_T16, off_, 0);
             }
 #pragma unroll
-            for (int rtl = 0; rtl < 2; ++rtl)
-                sf_pw16<32, 0, 1, false, true, false>(fs + 36 * rtl, lds, SF_R0, LSA, 0, 0, 0, SF_R1A, LSG, 16, 384, nullptr,
-                                                      16 * (8 * ps + 2 * wave + rtl));
+            for (int rtl = 0; rtl < 2; ++rtl) {
+                if constexpr (XO)
+                    sf_pw16_x3<4, 0, 1, false, true, false>(fs + 4 * NQ_T16 * rtl, lds, SF_R0, LSA, 0, 0, 0, SF_R1A, LSG, 16, 384,
+                                                            16 * (8 * ps + 2 * wave + rtl));
+                else
+                    sf_pw16<32, 0, 1, false, true, false>(fs + 4 * NQ_T16 * rtl, lds, SF_R0, LSA, 0, 0, 0, SF_R1A, LSG, 16, 384, nullptr,
+                                                          16 * (8 * ps + 2 * wave + rtl));
+            }
             SF_STAMP(10 + ps);
         }
         SF_SYNC();
@@ -712,10 +864,11 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
             SF_SYNC();
             SF_STAMP(8);
             // FGRU.conv (128 -> 64) + BN + ReLU
-            SF_TAKE(9);
-            if constexpr (TG) SF_REQUEST(13, A.o_tg_rz, wave);                // TGRU r/z rows, first pass
-            else SF_REQUEST(5, A.o_dpw[0], wave);                             // decoder.0 pw: 64 -> 64
-            sf_pw16<32, 0, 1, false, true>(fs, lds, SF_R0, LSA, 0, 0, 0, SF_R1A, LSA, 16, 64);
+            SF_TAKE(NQ_T16);
+            if constexpr (TG) SF_REQUEST(NQ_RZ, A.o_tg_rz, wave);             // TGRU r/z rows, first pass
+            else SF_REQUEST(NQ_D0, A.o_dpw[0], wave);                         // decoder.0 pw: 64 -> 64
+            if constexpr (XO) sf_pw16_x3<4, 0, 1, false, true>(fs, lds, SF_R0, LSA, 0, 0, 0, SF_R1A, LSA, 16, 64);
+            else sf_pw16<32, 0, 1, false, true>(fs, lds, SF_R0, LSA, 0, 0, 0, SF_R1A, LSA, 16, 64);
             sf_guards(lds, SF_R1A, 64, LSA, 16);
             if constexpr (TG) {
                 // ---------------- TGRU (network.py:150): x = R1A (64 x 16); h_{t-1} of this stream -> R1B as [128][LSG]
@@ -725,31 +878,44 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
                 // passes of one tile per wave -> R0 rows [0, 256) (stride LSG); n rows: W_in x + b_in -> rows [256, 384),
                 // W_hn h + b_hn -> rows [384, 512) (kept apart: r multiplies the latter only), two passes of 1 + 1 tiles
                 for (int ps = 0; ps < 4; ++ps) {
-                    SF_TAKE(13);
+                    SF_TAKE(NQ_RZ);
                     {
-                        // next r/z pass, or the first n pass: W_in tile (5 quads) + W_hn tile (9 quads) requested as 5 + 9
-                        const int off_ = ps < 3 ? A.o_tg_rz + (4 * (ps + 1) + wave) * 3328 : A.o_tg_in + wave * 1280;
-                        SF_REQUEST(5, off_, 0);
-                        const int off2_ = ps < 3 ? off_ + 1280 : A.o_tg_hn + wave * 2304;
-                        sf_load<9>(fp + 20, blob + off2_, lane);
+                        // next r/z pass, or the first n pass: W_in tile + W_hn tile, requested as NQ_IN + NQ_T16 quads (for an r/z
+                        // tile the same two loads fetch NQ_RZ + 1 contiguous quads)
+                        const int off_ = ps < 3 ? A.o_tg_rz + (4 * (ps + 1) + wave) * (NQ_RZ * 256) : A.o_tg_in + wave * (NQ_IN * 256);
+                        SF_REQUEST(NQ_IN, off_, 0);
+                        const int off2_ = ps < 3 ? off_ + NQ_IN * 256 : A.o_tg_hn + wave * (NQ_T16 * 256);
+                        sf_load<NQ_T16>(fp + 4 * NQ_IN, blob + off2_, lane);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    sf_pw16<16, 32, 1, false, true, false>(fs, lds, SF_R1A, LSA, 0, SF_R1B, LSG, SF_R0, LSG, 16, 512, nullptr,
-                                                           16 * (4 * ps + wave));
+                    if constexpr (XO)
+                        sf_pw16_x3<2, 4, 1, false, true, false>(fs, lds, SF_R1A, LSA, 0, SF_R1B, LSG, SF_R0, LSG, 16, 512,
+                                                                16 * (4 * ps + wave));
+                    else
+                        sf_pw16<16, 32, 1, false, true, false>(fs, lds, SF_R1A, LSA, 0, SF_R1B, LSG, SF_R0, LSG, 16, 512, nullptr,
+                                                               16 * (4 * ps + wave));
                 }
                 for (int ps = 0; ps < 2; ++ps) {
-                    SF_TAKE(14);
+                    SF_TAKE(NQ_IN + NQ_T16);
                     {
-                        const int off_ = ps < 1 ? A.o_tg_in + (4 + wave) * 1280 : A.o_tg_conv + wave * 2304;
-                        SF_REQUEST(5, off_, 0);
-                        const int off2_ = ps < 1 ? A.o_tg_hn + (4 + wave) * 2304 : A.o_tg_conv + wave * 2304 + 1280;
-                        sf_load<9>(fp + 20, blob + off2_, lane);
+                        // next n pass, or TGRU.conv (one tile, requested as NQ_IN quads + the ones behind them: contiguous)
+                        const int off_ = ps < 1 ? A.o_tg_in + (4 + wave) * (NQ_IN * 256) : A.o_tg_conv + wave * (NQ_T16 * 256);
+                        SF_REQUEST(NQ_IN, off_, 0);
+                        const int off2_ = ps < 1 ? A.o_tg_hn + (4 + wave) * (NQ_T16 * 256) : A.o_tg_conv + wave * (NQ_T16 * 256) + NQ_IN * 256;
+                        sf_load<NQ_T16>(fp + 4 * NQ_IN, blob + off2_, lane);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    sf_pw16<16, 0, 1, false, true, false>(fs, lds, SF_R1A, LSA, 0, 0, 0, SF_R0, LSG, 16, 512, nullptr,
-                                                          256 + 16 * (4 * ps + wave));
-                    sf_pw16<32, 0, 1, false, true, false>(fs + 20, lds, SF_R1B, LSG, 0, 0, 0, SF_R0, LSG, 16, 512, nullptr,
-                                                          384 + 16 * (4 * ps + wave));
+                    if constexpr (XO) {
+                        sf_pw16_x3<2, 0, 1, false, true, false>(fs, lds, SF_R1A, LSA, 0, 0, 0, SF_R0, LSG, 16, 512,
+                                                                256 + 16 * (4 * ps + wave));
+                        sf_pw16_x3<4, 0, 1, false, true, false>(fs + 4 * NQ_IN, lds, SF_R1B, LSG, 0, 0, 0, SF_R0, LSG, 16, 512,
+                                                                384 + 16 * (4 * ps + wave));
+                    } else {
+                        sf_pw16<16, 0, 1, false, true, false>(fs, lds, SF_R1A, LSA, 0, 0, 0, SF_R0, LSG, 16, 512, nullptr,
+                                                              256 + 16 * (4 * ps + wave));
+                        sf_pw16<32, 0, 1, false, true, false>(fs + 4 * NQ_IN, lds, SF_R1B, LSG, 0, 0, 0, SF_R0, LSG, 16, 512, nullptr,
+                                                              384 + 16 * (4 * ps + wave));
+                    }
                 }
                 SF_SYNC();
                 {
@@ -778,22 +944,25 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
                 }
                 SF_SYNC();
                 // TGRU.conv (128 -> 64) + BN + ReLU on h_t -> R1A (the decoder's input, as without the block)
-                SF_TAKE(9);
-                SF_REQUEST(5, A.o_dpw[0], wave);                              // decoder.0 pw: 64 -> 64
-                sf_pw16<32, 0, 1, false, true>(fs, lds, SF_R1B, LSG, 0, 0, 0, SF_R1A, LSA, 16, 64);
+                SF_TAKE(NQ_T16);
+                SF_REQUEST(NQ_D0, A.o_dpw[0], wave);                          // decoder.0 pw: 64 -> 64
+                if constexpr (XO) sf_pw16_x3<4, 0, 1, false, true>(fs, lds, SF_R1B, LSG, 0, 0, 0, SF_R1A, LSA, 16, 64);
+                else sf_pw16<32, 0, 1, false, true>(fs, lds, SF_R1B, LSG, 0, 0, 0, SF_R1A, LSA, 16, 64);
                 sf_guards(lds, SF_R1A, 64, LSA, 16);
             }
             SF_SYNC();
             // ---------------- decoder.0 (FirstTrCNN): pw 64 -> 64, ConvT k3 s2 -> L 31            network.py:60-76
-            SF_TAKE(5);
-            SF_REQUEST(13, A.o_ct[0], wave);
-            sf_pw16<16, 0, 1, false, true>(fs, lds, SF_R1A, LSA, 0, 0, 0, SF_R1B, LSA, 16, 64);
+            SF_TAKE(NQ_D0);
+            SF_REQUEST(NQ_C0, A.o_ct[0], wave);
+            if constexpr (XO) sf_pw16_x3<2, 0, 1, false, true>(fs, lds, SF_R1A, LSA, 0, 0, 0, SF_R1B, LSA, 16, 64);
+            else sf_pw16<16, 0, 1, false, true>(fs, lds, SF_R1A, LSA, 0, 0, 0, SF_R1B, LSA, 16, 64);
             sf_guards(lds, SF_R1B, 64, LSA, 16);
             SF_SYNC();
             sf_restore(lds, SF_R0, LSA, sk4, 128, 3);
-            SF_TAKE(13);
-            SF_REQUEST(13, A.o_dpw[1], wave);                                 // decoder.1 pw: 192 -> 64
-            sf_convT16<3, 2, 1, false>(fs, lds, SF_R1B, LSA, SF_R1A, LSA, 31, 0, 31);
+            SF_TAKE(NQ_C0);
+            SF_REQUEST(NQ_D, A.o_dpw[1], wave);                               // decoder.1 pw: 192 -> 64
+            if constexpr (XO) sf_convT16_x3<3, 2, 1, false>(fs, lds, SF_R1B, LSA, SF_R1A, LSA, 31, 0, 31);
+            else sf_convT16<3, 2, 1, false>(fs, lds, SF_R1B, LSA, SF_R1A, LSA, 31, 0, 31);
             sf_guards(lds, SF_R1A, 64, LSA, 31);
             SF_SYNC();
         }
@@ -807,10 +976,10 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
         for (int i = 1; i <= 4; ++i) {
             const int P = i == 1 ? 32 : (i == 4 ? 128 : 64);
             const int Lo = i == 1 ? 65 : (i == 2 ? 66 : (i == 3 ? 129 : 130));
-            SF_TAKE(13);
-            // same load sequence in every iteration (see the encoder loop): 21 quads are requested also for the 3-tap
-            // layers (13 used; the tile stride in the blob is that of the layer's own fragment count)
-            sf_load<21>(fp, blob + A.o_ct[i] + (size_t)wave * (((i & 1) ? 21 : 13) * 256), lane);
+            SF_TAKE(NQ_D);
+            // same load sequence in every iteration (see the encoder loop): the larger of the two transposed convs' fragment
+            // counts is requested for both (the tile stride in the blob is that of the layer's own count)
+            sf_load<NQ_CMAX>(fp, blob + A.o_ct[i] + (size_t)wave * (((i & 1) ? NQ_C5 : NQ_C3) * 256), lane);
             __builtin_amdgcn_sched_barrier(0);
             // skip tensor of the next block: enc3 (L 64), enc2 (L 64), enc1 (L 128), enc0 (64 x 128): requested a whole
             // block ahead (all workgroups restore at about the same time and the 45 MB of skip tensors live in the
@@ -822,24 +991,24 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
             const int skC = i == 4 ? 64 : 128, sklq = i <= 2 ? 4 : 5;
             sf_restore_request(rr, skn, skC, sklq);
             __builtin_amdgcn_sched_barrier(0);
-#ifdef SF_STAMPS
-            sf_pw16<16, 32, 2, false, true>(fs, lds, SF_R1A, LSA, i == 1 ? 0 : 1, SF_R0, LSA, SF_R1B, LSA, P, 64,
-                                            (i == 4 && blockIdx.x == 0 && n == 0)
-                                                ? (long long*)(A.scratch + (size_t)gridDim.x * SF_SKIP) + 32 : nullptr);
-#else
-            sf_pw16<16, 32, 2, false, true>(fs, lds, SF_R1A, LSA, i == 1 ? 0 : 1, SF_R0, LSA, SF_R1B, LSA, P, 64);
-#endif
+            if constexpr (XD) sf_pw16_x3<2, 4, 2, false, true>(fs, lds, SF_R1A, LSA, i == 1 ? 0 : 1, SF_R0, LSA, SF_R1B, LSA, P, 64);
+            else sf_pw16<16, 32, 2, false, true>(fs, lds, SF_R1A, LSA, i == 1 ? 0 : 1, SF_R0, LSA, SF_R1B, LSA, P, 64);
             sf_guards(lds, SF_R1B, 64, LSA, P);
             SF_SYNC();
             SF_STAMP(13 + 2 * i);                             // 15, 17, 19, 21: pointwise conv of block i done
-            SF_TAKE(21);
-            // next pw: decoder.(i+1) 192 -> 64 (13 quads per 16-row tile), or decoder.5 128 -> 8 (one padded tile of 9 quads)
-            sf_load<13>(fp, blob + A.o_dpw[i + 1] + (size_t)(i < 4 ? wave : 0) * (13 * 256), lane);
+            SF_TAKE(NQ_CMAX);
+            // next pw: decoder.(i+1) 192 -> 64, or decoder.5 128 -> 8 (one padded tile of NQ_T16 <= NQ_D quads)
+            sf_load<NQ_D>(fp, blob + A.o_dpw[i + 1] + (size_t)(i < 4 ? wave : 0) * (NQ_D * 256), lane);
             __builtin_amdgcn_sched_barrier(0);
             // the consumer (next block / decoder.5) reads positions [1, 1 + Pn) of this output
             const int Pn = i <= 2 ? 64 : 128;
-            if (i & 1) sf_convT16<5, 2, 2, true>(fs, lds, SF_R1B, LSA, SF_R1A, LSA, Lo, 1, Pn);
-            else sf_convT16<3, 1, 2, true>(fs, lds, SF_R1B, LSA, SF_R1A, LSA, Lo, 1, Pn);
+            if (i & 1) {
+                if constexpr (XC5) sf_convT16_x3<5, 2, 2, true>(fs, lds, SF_R1B, LSA, SF_R1A, LSA, Lo, 1, Pn);
+                else sf_convT16<5, 2, 2, true>(fs, lds, SF_R1B, LSA, SF_R1A, LSA, Lo, 1, Pn);
+            } else {
+                if constexpr (XC3) sf_convT16_x3<3, 1, 2, true>(fs, lds, SF_R1B, LSA, SF_R1A, LSA, Lo, 1, Pn);
+                else sf_convT16<3, 1, 2, true>(fs, lds, SF_R1B, LSA, SF_R1A, LSA, Lo, 1, Pn);
+            }
             sf_restore_commit(rr, lds, SF_R0, LSA, skC, sklq);
             sf_guards(lds, SF_R1A, 64, LSA, Lo);
             SF_SYNC();
@@ -848,8 +1017,9 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
         SF_STAMP(13);
         {   // ---------------- decoder.5 (LastTrCNN): pw 128 -> 8 (+BN+ReLU), ConvT 8 -> 8 k5 s2 -> 257, linear
             //                                                                                   network.py:102-120
-            SF_TAKE(9);
-            sf_pw16<16, 16, 2, true, false>(fs, lds, SF_R1A, LSA, 1, SF_R0, LSA, SF_R1B, LSA, 128, 8);
+            SF_TAKE(NQ_T16);
+            if constexpr (XO) sf_pw16_x3<2, 2, 2, true, false>(fs, lds, SF_R1A, LSA, 1, SF_R0, LSA, SF_R1B, LSA, 128, 8);
+            else sf_pw16<16, 16, 2, true, false>(fs, lds, SF_R1A, LSA, 1, SF_R0, LSA, SF_R1B, LSA, 128, 8);
             sf_guards(lds, SF_R1B, 8, LSA, 128);
             // ConvT weights [ci][co][k] + bias, staged as [co / 4][ci][k][co % 4]: a thread's four output channels of one
             // (ci, tap) are one wave-uniform 16-byte read
@@ -902,6 +1072,9 @@ __global__ __launch_bounds__(SF_T, 1) void stream_fwd_kernel(const SfArgs A) {
 
 extern "C" int trunet_stream_fwd_grid(int N);
 
+// which layer groups this build runs on the split path (bit mask: stream_fwd_x3.hip, SFX_MASK): the image must match it
+extern "C" int trunet_stream_fwd_x3_mask(void) { return SFX_MASK; }
+
 // Every section of the exported image must lie inside the blob, fragment over-reads (the kernel requests fixed-size blocks
 // of up to 21 quads per wave) included: a truncated or foreign artefact is refused here instead of faulting on the GPU.
 extern "C" int trunet_stream_fwd_x3_check(const int32_t* h_offsets, int n_offsets, int64_t blob_numel, int Cin) {
@@ -910,25 +1083,26 @@ extern "C" int trunet_stream_fwd_x3_check(const int32_t* h_offsets, int n_offset
     int64_t size[30];
     int i = 0;
     size[i++] = 64 * Cin * 5 + 64;                                     // first conv
-    size[i++] = 4 * 16 * T32;                                          // encoder.1 pw (K = 64: 4 K-steps x 3 planes + bias)
-    for (int k = 0; k < 4; ++k) size[i++] = 4 * 28 * T32;              // encoder.2..5 pw (K = 128: 8 x 3 + 4)
+    size[i++] = 4 * NQ_E1 * T32;                                       // encoder.1 pw (K = 64, 32-row tiles)
+    for (int k = 0; k < 4; ++k) size[i++] = 4 * NQ_E * T32;            // encoder.2..5 pw (K = 128)
     { const int ks[5] = {3, 5, 3, 5, 3}; for (int k = 0; k < 5; ++k) size[i++] = 128 * ks[k] + 128; }
-    size[i++] = 24 * 9 * T32;                                          // FGRU input projection (384 x 128, 16-row tiles)
+    size[i++] = 24 * NQ_T16 * T32;                                     // FGRU input projection (384 x 128, 16-row tiles)
     size[i++] = 2 * 24 * 128 * 4 + 384;                                // W_hh, b_hh
-    size[i++] = 4 * 9 * T32;                                           // FGRU.conv
-    size[i++] = 4 * 5 * T32;                                           // decoder.0 pw
-    for (int k = 0; k < 4; ++k) size[i++] = 4 * 13 * T32;              // decoder.1..4 pw (K = 192)
-    size[i++] = 1 * 9 * T32;                                           // decoder.5 pw (8 rows)
-    { const int taps[5] = {3, 5, 3, 5, 3}; for (int k = 0; k < 5; ++k) size[i++] = 4 * (4 * taps[k] + 1) * T32; }
+    size[i++] = 4 * NQ_T16 * T32;                                      // FGRU.conv
+    size[i++] = 4 * NQ_D0 * T32;                                       // decoder.0 pw
+    for (int k = 0; k < 4; ++k) size[i++] = 4 * NQ_D * T32;            // decoder.1..4 pw (K = 192)
+    size[i++] = 1 * NQ_T16 * T32;                                      // decoder.5 pw (8 rows)
+    size[i++] = 4 * NQ_C0 * T32;                                       // transposed convs: decoder.0 (k3 s2), then k5 / k3 / k5 / k3
+    size[i++] = 4 * NQ_C5 * T32; size[i++] = 4 * NQ_C3 * T32; size[i++] = 4 * NQ_C5 * T32; size[i++] = 4 * NQ_C3 * T32;
     size[i++] = 8 * 8 * 5 + 8;                                         // last ConvT
-    size[i++] = 16 * 13 * T32; size[i++] = 8 * 5 * T32; size[i++] = 8 * 9 * T32; size[i++] = 4 * 9 * T32;   // TGRU
+    size[i++] = 16 * NQ_RZ * T32; size[i++] = 8 * NQ_IN * T32; size[i++] = 8 * NQ_T16 * T32; size[i++] = 4 * NQ_T16 * T32;   // TGRU
     const bool tg = h_offsets[26] > 0;
     for (int k = 0; k < 30; ++k) {
         if (k >= 26 && !tg) { if (h_offsets[k] != 0) return TRUNET_EINVAL; continue; }
         const int64_t o = h_offsets[k];
         if (o < 0 || (o & 3)) return TRUNET_EINVAL;
         if (k >= 26 && o == 0) return TRUNET_EINVAL;
-        if (o + size[k] + 28 * T32 > blob_numel) return TRUNET_EINVAL;
+        if (o + size[k] + NQ_MAX * T32 > blob_numel) return TRUNET_EINVAL;
     }
     return TRUNET_OK;
 }
@@ -959,13 +1133,13 @@ extern "C" int trunet_stream_fwd_x3(const float* x, float* y, const float* blob,
     const int grid = trunet_stream_fwd_grid(N);
     const size_t ldsb = (size_t)SF_ARENA * sizeof(float);
     if (tg) {
-        if (hipFuncSetAttribute((const void*)stream_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)stream_fwd_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess)
             return TRUNET_ELAUNCH;
-        hipLaunchKernelGGL(stream_fwd_kernel<true>, dim3(grid), dim3(SF_T), ldsb, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(stream_fwd_x3_kernel<true>, dim3(grid), dim3(SF_T), ldsb, (hipStream_t)stream, a);
     } else {
-        if (hipFuncSetAttribute((const void*)stream_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)stream_fwd_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess)
             return TRUNET_ELAUNCH;
-        hipLaunchKernelGGL(stream_fwd_kernel<false>, dim3(grid), dim3(SF_T), ldsb, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(stream_fwd_x3_kernel<false>, dim3(grid), dim3(SF_T), ldsb, (hipStream_t)stream, a);
     }
     return trunet_launch_status();
 }

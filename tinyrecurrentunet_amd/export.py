@@ -142,10 +142,61 @@ def _frag_tiles_x3(Wm, bias):
     return np.concatenate(out)
 
 
-def x3_image(blob, offsets):
-    """The image `trunet_stream_fwd_x3` reads (round 4): the folded image with the pointwise weights of encoder.1 .. encoder.5 as
-    three bf16 fragment planes (exact three-term split of the folded fp32 weights; everything else bit for bit) -> (uint32 blob,
-    offsets)."""
+def _unfrag_tiles16(sec, M, K):
+    """Inverse of _frag_tiles16 -> (W (M, K), bias (M,)) float32."""
+    nrt = (M + 15) // 16
+    KQ = (K + 15) // 16 * 4
+    per = KQ * 64 + 256
+    sec = np.asarray(sec, dtype=np.float32)[:nrt * per].reshape(nrt, per)
+    lane = np.arange(64)
+    W = np.zeros((nrt * 16, 4 * KQ), dtype=np.float32)
+    b = np.zeros(nrt * 16, dtype=np.float32)
+    for rt in range(nrt):
+        A = sec[rt, :KQ * 64].reshape(KQ // 4, 64, 4).transpose(0, 2, 1).reshape(KQ, 64)          # (kq, lane)
+        rows = rt * 16 + (lane & 15)
+        W[rows[None, :], 4 * np.arange(KQ)[:, None] + (lane >> 4)[None, :]] = A
+        b[rt * 16 + 4 * (lane >> 4)[:, None] + np.arange(4)[None, :]] = sec[rt, KQ * 64:].reshape(64, 4)
+    return W[:M, :K], b[:M]
+
+
+def _frag_tiles16_x3(Wm, bias):
+    """Wm (M, K) float32, K a multiple of 32, bias (M,): per 16-row tile [K/32 K-steps x 3 planes: one quad each][1 quad of bias
+    (fp32 bits)].  Lane l holds the 8 bf16 values A[row l & 15][k = 32 ks + 8 (l >> 4) + 0..7] of a plane
+    (v_mfma_f32_16x16x32_bf16 A operand) -> uint32 array."""
+    M, K = Wm.shape
+    assert K % 32 == 0, K
+    nrt = (M + 15) // 16
+    KS = K // 32
+    Wp = np.zeros((nrt * 16, K), dtype=np.float32)
+    Wp[:M] = Wm
+    bp = np.zeros(nrt * 16, dtype=np.float32)
+    bp[:M] = bias
+    planes = _split3(Wp)
+    lane = np.arange(64)
+    out = []
+    for rt in range(nrt):
+        rows = rt * 16 + (lane & 15)
+        for ks in range(KS):
+            k0 = 32 * ks + 8 * (lane >> 4)
+            for pl in planes:
+                v = pl[rows[:, None], k0[:, None] + np.arange(8)[None, :]].astype(np.uint32)
+                out.append((v[:, 0::2] | (v[:, 1::2] << 16)).reshape(-1))
+        out.append(np.ascontiguousarray(bp[rt * 16 + 4 * (lane >> 4)[:, None] + np.arange(4)[None, :]]).reshape(-1).view(np.uint32))
+    return np.concatenate(out)
+
+
+# matrix sections of the folded image: index -> (rows, K, 32- or 16-row tiles, layer group bit of stream_fwd_x3.hip's SFX_MASK)
+_X3_SECTIONS = {1: (128, 64, 32, 1), 2: (128, 128, 32, 1), 3: (128, 128, 32, 1), 4: (128, 128, 32, 1), 5: (128, 128, 32, 1),
+                11: (384, 128, 16, 16), 13: (64, 128, 16, 16), 14: (64, 64, 16, 16),
+                15: (64, 192, 16, 2), 16: (64, 192, 16, 2), 17: (64, 192, 16, 2), 18: (64, 192, 16, 2), 19: (8, 128, 16, 16),
+                20: (64, 192, 16, 16), 21: (64, 320, 16, 8), 22: (64, 192, 16, 4), 23: (64, 320, 16, 8), 24: (64, 192, 16, 4),
+                26: (256, 192, 16, 16), 27: (128, 64, 16, 16), 28: (128, 128, 16, 16), 29: (64, 128, 16, 16)}
+
+
+def x3_image(blob, offsets, mask):
+    """The image `trunet_stream_fwd_x3` reads (round 4): the folded image with the matrix sections of the layer groups in `mask`
+    (_X3_SECTIONS; the library reports the mask it was built for: trunet_stream_fwd_x3_mask) as three bf16 fragment planes -- an
+    exact three-term split of the folded fp32 weights -- and everything else bit for bit -> (uint32 blob, offsets)."""
     blob = np.ascontiguousarray(np.asarray(blob, dtype=np.float32))
     offsets = np.asarray(offsets, dtype=np.int64)
     starts = sorted(set(int(offsets[i]) for i in range(N_OFFSETS) if i < 26 or offsets[i] > 0))
@@ -157,18 +208,22 @@ def x3_image(blob, offsets):
             continue
         a = int(offsets[i])
         raw = blob[a:bounds[a]]
-        if 1 <= i <= 5:                              # o_pw[5]: encoder.1 (K = 64), encoder.2..5 (K = 128), 128 rows each
-            W, b = _unfrag_tiles(raw, 128, 64 if i == 1 else 128)
-            raw = _frag_tiles_x3(W, b)
+        if i in _X3_SECTIONS and (_X3_SECTIONS[i][3] & mask):
+            M, K, tile, _ = _X3_SECTIONS[i]
+            if tile == 32:
+                raw = _frag_tiles_x3(*_unfrag_tiles(raw, M, K))
+            else:
+                raw = _frag_tiles16_x3(*_unfrag_tiles16(raw, M, K))
         else:
             raw = raw.view(np.uint32)
         offs.append(sum(len(x) for x in sec))
         sec.append(raw)
+    sec.append(np.zeros(64 * 256, dtype=np.uint32))     # fixed-size fragment requests over-read: they stay inside the image
     return np.concatenate(sec).astype(np.uint32), np.array(offs, dtype=np.int32)
 
 
 # which kernel a FoldedTRUNet launches by default (FoldedTRUNet.use_x3 switches an instance)
-STREAM_X3 = os.environ.get("TRUNET_STREAM_X3", "0") == "1"
+STREAM_X3 = os.environ.get("TRUNET_STREAM_X3", "1") == "1"
 
 N_OFFSETS = 30          # 26 sections of the stateless forward + 4 of the time-recurrent block (0 when not exported)
 
@@ -291,7 +346,7 @@ class FoldedTRUNet:
             self._make_x3()
 
     def _make_x3(self):
-        b3, o3 = x3_image(self.blob.cpu().numpy(), self.offsets)
+        b3, o3 = x3_image(self.blob.cpu().numpy(), self.offsets, L.lib().trunet_stream_fwd_x3_mask())
         rc = L.lib().trunet_stream_fwd_x3_check(o3.ctypes.data_as(C.POINTER(C.c_int32)), len(o3), len(b3), self.cin)
         if rc != L.TRUNET_OK:
             raise L.TrunetHipError("internal: the bf16-plane image fails its own bounds check")
