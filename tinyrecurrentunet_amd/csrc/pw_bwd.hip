@@ -52,6 +52,23 @@ __device__ __forceinline__ void pwb_split8(const f32x4 v0, const f32x4 v1, u32x4
 #define pwb_split8 ctx_split8
 #endif
 
+// (X3) dz is split ONCE, by the prologue pass that computes it, and stays in LDS as three bf16 planes in the bytes its two
+// operands (dy, z_y) occupied: physical piece pc of row r holds [hi of its 4 frames | mid of its 4 frames] (2 x 8 B), the same
+// piece of the z row [lo | unused] -- every thread writes inside the 32 bytes it has just read, so the pass stays in place
+// and free of cross-thread hazards.  The weight-gradient A fragment (K = frames) is then two 8-byte reads per plane, the
+// data-gradient B fragment (K = dz rows) two transposing reads per plane (ds_read_b64_tr_b16: 16 lanes fetch 4 rows x 16
+// frames and each receives ITS frame of the 4 rows), neither with any vector work: 40 of the 72 fragment splits per tile are
+// gone (the source rows have no spare bytes and are still split by the consuming wave).  0: every fragment split by its consumer.
+#ifndef PWB_DZ_PLANES
+#define PWB_DZ_PLANES 1
+#endif
+
+typedef short pwb_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x2 pwb_tr16(const float* p) {
+    const pwb_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) pwb_s16x4*)p);
+    return __builtin_bit_cast(u32x2, v);
+}
+
 constexpr int WFC = 32;          // frames per tile
 constexpr int PMAXT = 4;         // weight-gradient accumulator tiles per wave (waves 0-3)
 constexpr int PSW = 6;           // source DMA row groups per loader wave (sum of channels <= 192)
@@ -162,6 +179,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
     const int c = lane & 31;
+    constexpr bool DZP = X3 && PWB_DZ_PLANES && !(PWB_ABL & 64);      // dz as bf16 planes (see PWB_DZ_PLANES)
     constexpr int MA = 2 * AK;                // padded dz rows
     constexpr int nrt = MA / 32;
     constexpr int DZR = 2 * MA;               // rows of the dz block (dy, z)
@@ -365,7 +383,15 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
                                 sacc += v[e];
                             }
                             bsum[i] += sacc;
-                            *(f32x4*)pz = v;
+                            if constexpr (DZP) {
+                                unsigned h0, m0, l0, h1, m1, l1;
+                                ctx_split2(v[0], v[1], h0, m0, l0);
+                                ctx_split2(v[2], v[3], h1, m1, l1);
+                                *(u32x4*)pz = u32x4{h0, h1, m0, m1};                    // [hi x 4 frames | mid x 4 frames]
+                                *(u32x2*)(pz + MA * WFC) = u32x2{l0, l1};               // lo, in the z row's piece
+                            } else {
+                                *(f32x4*)pz = v;
+                            }
                         }
                     }
                 } else {
@@ -408,8 +434,19 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
                     for (int qq = 0; qq < WFC / 16; ++qq) {
                         // this lane's 8 frames of the K-step: 16 qq + 8 h .. + 7 = pieces 4 qq + 2 h, 4 qq + 2 h + 1 of its row
                         u32x4 a0, a1, a2;
-                        pwb_split8(*(const f32x4*)(S + pwb_off(ra, 4 * qq + 2 * h)),
-                                   *(const f32x4*)(S + pwb_off(ra, 4 * qq + 2 * h + 1)), a0, a1, a2);
+                        if constexpr (DZP) {
+                            // planes of the dz row: [hi | mid] in the row's own pieces, lo in the z row's
+                            const float* p0 = S + pwb_off(ra, 4 * qq + 2 * h);
+                            const float* p1 = S + pwb_off(ra, 4 * qq + 2 * h + 1);
+                            const u32x4 q0 = *(const u32x4*)p0, q1 = *(const u32x4*)p1;
+                            const u32x2 l0 = *(const u32x2*)(p0 + MA * WFC), l1 = *(const u32x2*)(p1 + MA * WFC);
+                            a0 = u32x4{q0[0], q0[1], q1[0], q1[1]};
+                            a1 = u32x4{q0[2], q0[3], q1[2], q1[3]};
+                            a2 = u32x4{l0[0], l0[1], l1[0], l1[1]};
+                        } else {
+                            pwb_split8(*(const f32x4*)(S + pwb_off(ra, 4 * qq + 2 * h)),
+                                       *(const f32x4*)(S + pwb_off(ra, 4 * qq + 2 * h + 1)), a0, a1, a2);
+                        }
 #pragma unroll
                         for (int i = 0; i < PMAXT; ++i) {
                             if (rb_run[i] >= 0 && !(PWB_ABL & 16)) {
@@ -494,6 +531,11 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
         // (s_setprio 1 for these waves was measured: 4 % slower at 128 channels, neutral at 64)
         const int j = wave - 4;
         const int e0 = pwb_e0(h, c);
+        // (DZP) this lane's two transposing reads of a K-step of 16 dz rows: lane (G = lane >> 4, i = lane & 15) fetches the
+        // 4 frames of logical piece 4 (G & 1) + (i & 3) of row 8 (G >> 1) + 4 t + (i >> 2) (t = 0, 1) and receives frame
+        // 16 (G & 1) + i = c of the rows 8 h + 4 t .. + 3: float offsets inside the slot, K-step 0
+        const int trr = 8 * (lane >> 5) + ((lane & 15) >> 2), trp = 4 * ((lane >> 4) & 1) + (lane & 3);
+        const int trb0 = pwb_off(trr, trp), trb1 = pwb_off(trr + 4, trp);
         if constexpr (KSPLIT) {
             constexpr int AH = AK / 2;                 // k-pairs per wave
             const int rt = j & 1, kh = j >> 1;         // row tile, K half (uniform)
@@ -593,6 +635,18 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
                         if constexpr (X3) {
                             // B fragment of K-step ks: frame c, dz rows 2 kh AH + 16 ks + 8 h + j (j < 8); a row keeps its 16-byte
                             // pieces XOR-swizzled by (row >> 1) & 7 = (4 h + (j >> 1)) & 7 (the K-step's first row is a multiple of 16)
+                            if constexpr (DZP) {
+#pragma unroll
+                                for (int ks = 0; ks < ((PWB_ABL & 32) ? 1 : AH / 8); ++ks) {
+                                    const float* q0 = S + trb0 + (2 * kh * AH + 16 * ks) * WFC;
+                                    const float* q1 = S + trb1 + (2 * kh * AH + 16 * ks) * WFC;
+                                    const u32x2 h0 = pwb_tr16(q0), h1 = pwb_tr16(q1), m0 = pwb_tr16(q0 + 2), m1 = pwb_tr16(q1 + 2);
+                                    const u32x2 l0 = pwb_tr16(q0 + MA * WFC), l1 = pwb_tr16(q1 + MA * WFC);
+                                    const u32x4 b0 = {h0[0], h0[1], h1[0], h1[1]}, b1 = {m0[0], m0[1], m1[0], m1[1]},
+                                                b2 = {l0[0], l0[1], l1[0], l1[1]};
+                                    CTX_MF6(dacc, ap[ks][0], ap[ks][1], ap[ks][2], b0, b1, b2);
+                                }
+                            } else {
                             const float* Sb = S + (size_t)(2 * kh * AH + 8 * h) * WFC + (c & 3);
 #pragma unroll
                             for (int ks = 0; ks < ((PWB_ABL & 32) ? 1 : AH / 8); ++ks) {
@@ -605,6 +659,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
                                 u32x4 b0, b1, b2;
                                 pwb_split8(x0, x1, b0, b1, b2);
                                 CTX_MF6(dacc, ap[ks][0], ap[ks][1], ap[ks][2], b0, b1, b2);
+                            }
                             }
                         } else {
                             const float* Sb = S + (size_t)kh * AH * (2 * WFC) + h * WFC + (c & 3);
@@ -764,6 +819,18 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
             const int cpc = c >> 2;
             if constexpr (X3) {
                 // B fragment of K-step ks: frame c, dz rows 16 ks + 8 h + j (j < 8); swizzle term of a row: (4 h + (j >> 1)) & 7
+                if constexpr (DZP) {
+#pragma unroll
+                    for (int ks = 0; ks < ((PWB_ABL & 32) ? 1 : AK / 8); ++ks) {
+                        const float* q0 = S + trb0 + 16 * ks * WFC;
+                        const float* q1 = S + trb1 + 16 * ks * WFC;
+                        const u32x2 h0 = pwb_tr16(q0), h1 = pwb_tr16(q1), m0 = pwb_tr16(q0 + 2), m1 = pwb_tr16(q1 + 2);
+                        const u32x2 l0 = pwb_tr16(q0 + MA * WFC), l1 = pwb_tr16(q1 + MA * WFC);
+                        const u32x4 b0 = {h0[0], h0[1], h1[0], h1[1]}, b1 = {m0[0], m0[1], m1[0], m1[1]},
+                                    b2 = {l0[0], l0[1], l1[0], l1[1]};
+                        CTX_MF6(dacc, fr.ap[ks][0], fr.ap[ks][1], fr.ap[ks][2], b0, b1, b2);
+                    }
+                } else {
                 const float* Sb = S + 8 * h * WFC + (c & 3);
 #pragma unroll
                 for (int ks = 0; ks < ((PWB_ABL & 32) ? 1 : AK / 8); ++ks) {
@@ -776,6 +843,7 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
                     u32x4 b0, b1, b2;
                     pwb_split8(x0, x1, b0, b1, b2);
                     CTX_MF6(dacc, fr.ap[ks][0], fr.ap[ks][1], fr.ap[ks][2], b0, b1, b2);
+                }
                 }
             } else {
                 const float* Sb = S + h * WFC + (c & 3);
