@@ -19,6 +19,23 @@ constexpr int CT_F = 32;            // frames per tile
 constexpr int CT_C = 64;            // channels (both sides)
 constexpr int CT_SET = CT_C * CT_F; // floats per row set (8 KB)
 constexpr int CT_GRID = TRUNET_NUM_CU;
+constexpr int CT_LO = CT_C * 16;    // floats per row set of the lo-plane ring (8 bytes per 4 frames)
+
+// (round 4, as in pw_bwd.hip) dz is split ONCE, by the prologue pass that computes it: the dz ring keeps [hi | mid] of a
+// piece's 4 frames in the piece's own 16 bytes, a second ring of 4 KB slots the lo plane.  The weight-gradient B fragments
+// (K = frames) are then 8-byte reads, the data-gradient B fragments (K = dz rows) transposing reads (ds_read_b64_tr_b16),
+// neither with vector work; only the source rows are still split by the wave that consumes them.  Needs (K + 2 S) x 4 KB
+// more LDS: k3 s1 fits (126 KB); k3 s2 (166 KB) and k5 s2 (190 KB) do not and keep the consumer-side split.
+template <int K, int S>
+constexpr bool ct_dzp() { return K == 3 && S == 1; }
+
+typedef short ct_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x2 ct_tr16(const float* p) {
+    const ct_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ct_s16x4*)p);
+    return __builtin_bit_cast(u32x2, v);
+}
+// float offset of the 8 lo bytes of logical piece `pc` of row `r` inside a lo-ring slot (same swizzle as the row set)
+__device__ __forceinline__ int ct_lo_off(int r, int pc) { return r * 16 + 2 * (pc ^ ((r >> 1) & 7)); }
 
 typedef __attribute__((address_space(3))) void* ct_lds_ptr_t;
 
@@ -54,7 +71,9 @@ __global__ __launch_bounds__(512, 1) void convt_bwd_x3_kernel(const trunet_convt
     float* ZST = DZ + RDZ * CT_SET;                 // [ZS][64][32]
     float* SRC = ZST + ZS * CT_SET;                 // [RS][64][32]
     float* PART = SRC + RS * CT_SET;                // [2 parity][2 ci tiles][16][64]
-    f32x4* CA = (f32x4*)(PART + 2 * 2 * 16 * 64);   // [64] (ca, cb, cc, 0) of dz
+    constexpr bool DZP = ct_dzp<K, S>();
+    float* LO = PART + 2 * 2 * 16 * 64;             // (DZP) [RDZ][64][16]: lo plane of the dz ring
+    f32x4* CA = (f32x4*)(LO + (DZP ? RDZ * CT_LO : 0));   // [64] (ca, cb, cc, 0) of dz
     f32x4* CB = CA + CT_C;                          // [64] (sc, sh, mean, 0) of the source
 
     const int tid = threadIdx.x;
@@ -136,7 +155,15 @@ __global__ __launch_bounds__(512, 1) void convt_bwd_x3_kernel(const trunet_convt
                         s += v[e];
                     }
                     bsum[i] += s;
-                    *(f32x4*)(dst + o) = v;
+                    if constexpr (DZP) {
+                        unsigned h0, m0, l0, h1, m1, l1;
+                        ctx_split2(v[0], v[1], h0, m0, l0);
+                        ctx_split2(v[2], v[3], h1, m1, l1);
+                        *(u32x4*)(dst + o) = u32x4{h0, h1, m0, m1};
+                        *(u32x2*)(LO + (p % RDZ) * CT_LO + row_[i] * 16 + 2 * pc) = u32x2{l0, l1};
+                    } else {
+                        *(f32x4*)(dst + o) = v;
+                    }
                 }
             }
         };
@@ -181,10 +208,21 @@ __global__ __launch_bounds__(512, 1) void convt_bwd_x3_kernel(const trunet_convt
                         const int p = q * S - PAD + k;
                         if (p >= 0 && p < Lout) {
                             const float* Dp = DZ + (p % RDZ) * CT_SET;
-                            const f32x4 bv0 = *(const f32x4*)(Dp + ct_off(rb, 4 * qq + 2 * h));
-                            const f32x4 bv1 = *(const f32x4*)(Dp + ct_off(rb, 4 * qq + 2 * h + 1));
                             u32x4 b0, b1, b2;
-                            ctx_split8(bv0, bv1, b0, b1, b2);
+                            if constexpr (DZP) {
+                                const float* Lp = LO + (p % RDZ) * CT_LO;
+                                const u32x4 q0 = *(const u32x4*)(Dp + ct_off(rb, 4 * qq + 2 * h));
+                                const u32x4 q1 = *(const u32x4*)(Dp + ct_off(rb, 4 * qq + 2 * h + 1));
+                                const u32x2 l0 = *(const u32x2*)(Lp + ct_lo_off(rb, 4 * qq + 2 * h));
+                                const u32x2 l1 = *(const u32x2*)(Lp + ct_lo_off(rb, 4 * qq + 2 * h + 1));
+                                b0 = u32x4{q0[0], q0[1], q1[0], q1[1]};
+                                b1 = u32x4{q0[2], q0[3], q1[2], q1[3]};
+                                b2 = u32x4{l0[0], l0[1], l1[0], l1[1]};
+                            } else {
+                                const f32x4 bv0 = *(const f32x4*)(Dp + ct_off(rb, 4 * qq + 2 * h));
+                                const f32x4 bv1 = *(const f32x4*)(Dp + ct_off(rb, 4 * qq + 2 * h + 1));
+                                ctx_split8(bv0, bv1, b0, b1, b2);
+                            }
                             CTX_MF6(acc[k], a0, a1, a2, b0, b1, b2);
                         }
                     }
@@ -229,6 +267,7 @@ __global__ __launch_bounds__(512, 1) void convt_bwd_x3_kernel(const trunet_convt
         // =============================================================== data gradient
         const int jj = wave - 4;
         const int cit = jj & 1, chf = jj >> 1;           // ci tile, co half
+        const int trr = 8 * (lane >> 5) + ((lane & 15) >> 2), trp = 4 * ((lane >> 4) & 1) + (lane & 3);     // (DZP) transposing reads
         // W^T fragments: A[i = ci][k = co] per tap: af[k][kk] = W[ci = 32 cit + (lane & 31)][co = 32 chf + 2 kk + h][k]
         // W^T fragment planes: lane (row ci = 32 cit + c, k = co = 32 chf + 16 ks + 8 h + j, j < 8) per tap and K-step
         u32x4 A0[K][2], A1[K][2], A2[K][2];
@@ -291,6 +330,22 @@ __global__ __launch_bounds__(512, 1) void convt_bwd_x3_kernel(const trunet_convt
                     if (p >= 0 && p < Lout) {
                         // B fragment of K-step ks: this lane's frame c, dz rows 32 chf + 16 ks + 8 h + j (j < 8); row r keeps
                         // its 16-byte pieces XOR-swizzled by (r >> 1) & 7 = (4 h + (j >> 1)) & 7 (32 chf + 16 ks is a multiple of 16)
+                        if constexpr (DZP) {
+                            // lane (G = lane >> 4, i = lane & 15) fetches the 4 frames of logical piece 4 (G & 1) + (i & 3) of row
+                            // 32 chf + 16 ks + 8 h + 4 t + (i >> 2) and receives frame c of the rows 8 h + 4 t .. + 3 (t = 0, 1)
+                            const float* Dq = DZ + (p % RDZ) * CT_SET;
+                            const float* Lq = LO + (p % RDZ) * CT_LO;
+#pragma unroll
+                            for (int ks = 0; ks < 2; ++ks) {
+                                const int r0 = chf * 32 + 16 * ks + trr;
+                                const u32x2 h0 = ct_tr16(Dq + ct_off(r0, trp)), h1 = ct_tr16(Dq + ct_off(r0 + 4, trp));
+                                const u32x2 m0 = ct_tr16(Dq + ct_off(r0, trp) + 2), m1 = ct_tr16(Dq + ct_off(r0 + 4, trp) + 2);
+                                const u32x2 l0 = ct_tr16(Lq + ct_lo_off(r0, trp)), l1 = ct_tr16(Lq + ct_lo_off(r0 + 4, trp));
+                                const u32x4 b0 = {h0[0], h0[1], h1[0], h1[1]}, b1 = {m0[0], m0[1], m1[0], m1[1]},
+                                            b2 = {l0[0], l0[1], l1[0], l1[1]};
+                                CTX_MF6(dacc, A0[k][ks], A1[k][ks], A2[k][ks], b0, b1, b2);
+                            }
+                        } else {
                         const float* Sb = DZ + (p % RDZ) * CT_SET + (chf * 32 + 8 * h) * CT_F + (c & 3);
                         const int cpc = c >> 2;
 #pragma unroll
@@ -304,6 +359,7 @@ __global__ __launch_bounds__(512, 1) void convt_bwd_x3_kernel(const trunet_convt
                             u32x4 b0, b1, b2;
                             ctx_split8(x0, x1, b0, b1, b2);
                             CTX_MF6(dacc, A0[k][ks], A1[k][ks], A2[k][ks], b0, b1, b2);
+                        }
                         }
                     }
                 }
@@ -340,7 +396,10 @@ __global__ __launch_bounds__(512, 1) void convt_bwd_x3_kernel(const trunet_convt
 template <int K, int S>
 int ctx_launch(const trunet_convt_bwd_args* h, hipStream_t st) {
     constexpr int RDZ = K + 2 * S, ZS = 2 * S, RS = 4;
-    const size_t lds = ((size_t)(RDZ + ZS + RS) * CT_SET + 2 * 2 * 16 * 64) * sizeof(float) + 2 * CT_C * sizeof(f32x4);
+    const size_t lds = ((size_t)(RDZ + ZS + RS) * CT_SET + 2 * 2 * 16 * 64 + (ct_dzp<K, S>() ? RDZ * CT_LO : 0)) * sizeof(float) +
+                       2 * CT_C * sizeof(f32x4);
+    static_assert(!ct_dzp<K, S>() || ((size_t)(RDZ + ZS + RS) * CT_SET + 2 * 2 * 16 * 64 + RDZ * CT_LO) * sizeof(float) +
+                                         2 * CT_C * sizeof(f32x4) <= 160 * 1024, "LDS");
     auto kern = convt_bwd_x3_kernel<K, S>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return TRUNET_ELAUNCH;
