@@ -60,13 +60,24 @@ __device__ __forceinline__ void pwb_split8(const f32x4 v0, const f32x4 v1, u32x4
 // frames and each receives ITS frame of the 4 rows), neither with any vector work: 40 of the 72 fragment splits per tile are
 // gone (the source rows have no spare bytes and are still split by the consuming wave).  0: every fragment split by its consumer.
 #ifndef PWB_DZ_PLANES
-#define PWB_DZ_PLANES 1
+#define PWB_DZ_PLANES 2          // 1: dz only; 2: the source rows of the 128-row layers too (SRCP below)
 #endif
 
 typedef short pwb_s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ u32x2 pwb_tr16(const float* p) {
     const pwb_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) pwb_s16x4*)p);
     return __builtin_bit_cast(u32x2, v);
+}
+
+// (SRCP) the fp32 activation at float offset F of a slot (a source row's element: row * 32 + 4 * physical piece + frame & 3)
+// from its planes: hi / mid are halfwords (frame & 3) of the piece's first / second 8 bytes, lo of the second half of the same
+// piece MA rows further up (the z row); zrow_h = that distance in halfwords (negative).  Exact: hi + mid + lo in fp32.
+__device__ __forceinline__ float pwb_act3(const float* S, int F, int c3, int zrow_h) {
+    const unsigned short* hp = (const unsigned short*)S + 2 * F - c3;
+    const float hi = __builtin_bit_cast(float, (unsigned)hp[0] << 16);
+    const float mid = __builtin_bit_cast(float, (unsigned)hp[4] << 16);
+    const float lo = __builtin_bit_cast(float, (unsigned)hp[zrow_h + 4] << 16);
+    return hi + mid + lo;
 }
 
 constexpr int WFC = 32;          // frames per tile
@@ -180,6 +191,12 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
     const int h = lane >> 5;
     const int c = lane & 31;
     constexpr bool DZP = X3 && PWB_DZ_PLANES && !(PWB_ABL & 64);      // dz as bf16 planes (see PWB_DZ_PLANES)
+    // ... and the SOURCE rows as well where their lo plane fits into the unused second half of the z pieces (one z row per
+    // source row: layers with 128 dz rows and <= 128 source channels -- the encoder): [hi | mid] in the row's own pieces,
+    // lo in bytes 8..15 of the same piece of z row (source row index).  The thread that transforms source row s also owns
+    // dz row s and has consumed that z piece one part earlier.  Every MFMA fragment of these layers is then read, not split;
+    // the epilogue rebuilds the activation it masks with from the three planes (exact).
+    constexpr bool SRCP = DZP && AK == 64 && !SEC && PWB_DZ_PLANES >= 2;
     constexpr int MA = 2 * AK;                // padded dz rows
     constexpr int nrt = MA / 32;
     constexpr int DZR = 2 * MA;               // rows of the dz block (dy, z)
@@ -403,7 +420,15 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
                             f32x4 v = *(f32x4*)pz;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], k[0], k[1]), k[2]);
-                            *(f32x4*)pz = v;
+                            if constexpr (SRCP) {
+                                unsigned h0, m0, l0, h1, m1, l1;
+                                ctx_split2(v[0], v[1], h0, m0, l0);
+                                ctx_split2(v[2], v[3], h1, m1, l1);
+                                *(u32x4*)pz = u32x4{h0, h1, m0, m1};
+                                *(u32x2*)(pz - MA * WFC + 2) = u32x2{l0, l1};           // z row (source row index), bytes 8..15
+                            } else {
+                                *(f32x4*)pz = v;
+                            }
                         }
                     }
                 }
@@ -451,8 +476,18 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
                         for (int i = 0; i < PMAXT; ++i) {
                             if (rb_run[i] >= 0 && !(PWB_ABL & 16)) {
                                 u32x4 b0, b1, b2;
-                                pwb_split8(*(const f32x4*)(S + pwb_off(rb_run[i] + c, 4 * qq + 2 * h)),
-                                           *(const f32x4*)(S + pwb_off(rb_run[i] + c, 4 * qq + 2 * h + 1)), b0, b1, b2);
+                                if constexpr (SRCP) {
+                                    const float* p0 = S + pwb_off(rb_run[i] + c, 4 * qq + 2 * h);
+                                    const float* p1 = S + pwb_off(rb_run[i] + c, 4 * qq + 2 * h + 1);
+                                    const u32x4 q0 = *(const u32x4*)p0, q1 = *(const u32x4*)p1;
+                                    const u32x2 l0 = *(const u32x2*)(p0 - MA * WFC + 2), l1 = *(const u32x2*)(p1 - MA * WFC + 2);
+                                    b0 = u32x4{q0[0], q0[1], q1[0], q1[1]};
+                                    b1 = u32x4{q0[2], q0[3], q1[2], q1[3]};
+                                    b2 = u32x4{l0[0], l0[1], l1[0], l1[1]};
+                                } else {
+                                    pwb_split8(*(const f32x4*)(S + pwb_off(rb_run[i] + c, 4 * qq + 2 * h)),
+                                               *(const f32x4*)(S + pwb_off(rb_run[i] + c, 4 * qq + 2 * h + 1)), b0, b1, b2);
+                                }
                                 CTX_MF6(acc[i], a0, a1, a2, b0, b1, b2);
                             }
                         }
@@ -623,7 +658,10 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
                         for (int i = 0; i < 8; ++i) { zv[i] = 0.f; ov[i] = 0.f; }
                         if (uflags & TRUNET_DG_MASK) {        // the source's activation a = max(c0 z + c1, lo) as staged in the slot
 #pragma unroll
-                            for (int i = 0; i < 8; ++i) zv[i] = S[lrow * WFC + pwb_erow(i) + (e0 ^ pwb_ekr(i))];
+                            for (int i = 0; i < 8; ++i) {
+                                if constexpr (SRCP) zv[i] = pwb_act3(S, lrow * WFC + pwb_erow(i) + (e0 ^ pwb_ekr(i)), c & 3, -MA * WFC * 2);
+                                else zv[i] = S[lrow * WFC + pwb_erow(i) + (e0 ^ pwb_ekr(i))];
+                            }
                         }
                         if ((uflags & TRUNET_DG_ACCUM) && !(PWB_ABL & 1)) {
 #pragma unroll
@@ -808,7 +846,10 @@ __global__ __launch_bounds__(512, 2) void pw_bwd_kernel(const trunet_pwbwd_args 
             for (int r = 0; r < 16; ++r) { zv[r] = 0.f; ov[r] = 0.f; }
             if (u.flags & TRUNET_DG_MASK) {       // the source's activation a = max(c0 z + c1, lo) as staged in the slot
 #pragma unroll
-                for (int r = 0; r < 16; ++r) zv[r] = S[dr.lrow * WFC + pwb_erow(r) + (e0 ^ pwb_ekr(r))];
+                for (int r = 0; r < 16; ++r) {
+                    if constexpr (SRCP) zv[r] = pwb_act3(S, dr.lrow * WFC + pwb_erow(r) + (e0 ^ pwb_ekr(r)), c & 3, -MA * WFC * 2);
+                    else zv[r] = S[dr.lrow * WFC + pwb_erow(r) + (e0 ^ pwb_ekr(r))];
+                }
             }
             if ((u.flags & TRUNET_DG_ACCUM) && !(PWB_ABL & 1)) {
 #pragma unroll
